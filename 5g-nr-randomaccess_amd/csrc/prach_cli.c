@@ -1,0 +1,167 @@
+/* prach_cli.c — `prach_sim`: host-C driver with the reference's command-line surface
+ * (RandomAccessWithNOMA.c:90-206, README.md:43-87) on top of the C ABI (include/prach.h).
+ *
+ * Same (flag, value) pair parsing, same messages and exit(-1) on bad values, same seed loop x
+ * nUE sweep (WithNOMA:216-221), same stdout block and result files; the per-subframe loop itself
+ * runs on the MI355X through prach_run_trials().  Both the spellings the code accepts (-rc, -mrc,
+ * -bs, -ut) and the ones README.md documents (-r, -m, -u) are taken; `-d 2` selects Beta as the
+ * README says (the reference's validation rejects it).
+ *
+ * Extensions (not in the reference): --program beta|withnoma, --rng glibc|philox, --nue N,
+ * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N.
+ */
+#define _GNU_SOURCE
+#include "../../include/prach.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static void usage_and_exit(void) { /* text of WithNOMA:160-202 */
+    printf("--times         -t : Simulation times (int)\n");
+    printf("                     Simulation count must be greater than zero.\n");
+    printf("                     Default 1\n\n");
+    printf("--distribution  -d : Traffic model (1 or 2)\n");
+    printf("                     1: traffic model 1 (Uniform distribution)\n");
+    printf("                     2: traffic model 2 (Beta distribution)\n\n");
+    printf("--preambles     -p : Number of preambles (int)\n");
+    printf("                     Number of preamble must be greater than zero.\n");
+    printf("                     Default 54\n\n");
+    printf("--backoff       -b : Backoff indicator (int)\n");
+    printf("                     Backoff indicator must be greater than zero.\n");
+    printf("                     Default 20\n\n");
+    printf("--grant         -g : The number of Up Link Grant per RAR (int)\n");
+    printf("                     The number of Up Link Grant per RAR must be greater than zero.\n");
+    printf("                     Default 12\n\n");
+    printf("--rarCount      -r : RAR window size (int)\n");
+    printf("                     The maximum RAR window size must be greater than zero.\n");
+    printf("                     Default 5\n\n");
+    printf("--maxRar        -m : Maximum retransmission (int)\n");
+    printf("                     Maximum retransmissions must be greater than zero.\n");
+    printf("                     Default 10\n\n");
+    printf("--subframe      -s : Subframe units (int)\n");
+    printf("                     The size of the subframe must be at least 5. (float)\n");
+    printf("                     Default 5\n\n");
+    printf("--cell          -c : Cell radius Size\n");
+    printf("                     The radius of the cell is entered in diameter units and must be greater than 400m.\n");
+    printf("                     Default 400.0\n\n");
+    printf("--hbs           -b : Height of BS from ground (float)\n");
+    printf("                     The height of the BS must be between 10m and 20m.\n");
+    printf("                     Default 10.0\n\n");
+    printf("--hut           -u : Height of UE from ground (float)\n");
+    printf("                     The height of the UE must be between 1.5m and 22.5m.\n");
+    printf("                     Default 1.8\n\n");
+    exit(-1);
+}
+
+static int is(const char *a, const char *l, const char *s1, const char *s2) {
+    return strcmp(a, l) == 0 || (s1 && strcmp(a, s1) == 0) || (s2 && strcmp(a, s2) == 0);
+}
+static void die(const char *msg) { printf("%s", msg); exit(-1); }
+
+int main(int argc, char *argv[]) {
+    int randomMax = 1, variant = PRACH_VARIANT_WITHNOMA_C, rng = PRACH_RNG_GLIBC, device = 0, want_logs = 1;
+    int sweep_lo = 10000, sweep_hi = 100000, sweep_step = 10000; /* WithNOMA:221 */
+    const char *outdir = ".";
+    /* --program must be known before the defaults are laid down */
+    for (int i = 1; i + 1 < argc; i += 2)
+        if (strcmp(argv[i], "--program") == 0) variant = strcmp(argv[i + 1], "beta") == 0 ? PRACH_VARIANT_BETA_C : PRACH_VARIANT_WITHNOMA_C;
+    prach_cfg base;
+    prach_cfg_defaults(&base, variant);
+
+    for (int i = 1; i < argc; i += 2) {
+        const char *a = argv[i];
+        if (i + 1 >= argc) usage_and_exit(); /* the reference dereferences NULL here; we print the usage */
+        const char *v = argv[i + 1];
+        if (is(a, "--times", "-t", NULL)) {
+            if (atoi(v) < 1) die("Simulation count must be greater than zero.");
+            randomMax = atoi(v);
+        } else if (is(a, "--distribution", "-d", NULL)) {
+            if (atoi(v) != 1 && atoi(v) != 0 && atoi(v) != 2) die("Traffic model just choose 1 or 2");
+            base.uniform = atoi(v) == 1;
+        } else if (is(a, "--preambles", "-p", NULL)) {
+            if (atoi(v) < 1) die("Number of preamble must be greater than zero.");
+            base.nPreamble = atoi(v);
+        } else if (is(a, "--backoff", "-b", NULL)) {
+            if (atoi(v) < 1) die("Backoff indicator must be greater than zero.");
+            base.backoff = atoi(v);
+        } else if (is(a, "--grant", "-g", NULL)) {
+            if (atoi(v) < 1) die("The number of Up Link Grant per RAR must be greater than zero.");
+            base.nGrantUL = atoi(v);
+        } else if (is(a, "--rarCount", "-rc", "-r")) {
+            if (atoi(v) < 1) die("The maximum RAR window size must be greater than zero.");
+            base.maxRarWindow = atoi(v) + 1; /* WithNOMA:128 */
+        } else if (is(a, "--maxRar", "-mrc", "-m")) {
+            if (atoi(v) < 1) die("Maximum retransmissions must be greater than zero.");
+            base.maxMsg2TxCount = atoi(v) - 1; /* WithNOMA:134 */
+        } else if (is(a, "--subframe", "-s", NULL)) {
+            if (atoi(v) < 5) die("The size of the subframe must be at least 5.");
+            base.accessTime = atoi(v);
+        } else if (is(a, "--cell", "-c", NULL)) {
+            if (atof(v) < 400.0) die("The radius of the cell is entered in diameter units and must be greater than 400m.");
+            base.cellRadius = (float)atof(v);
+        } else if (is(a, "--hbs", "-bs", NULL)) {
+            if (atof(v) < 10.0 || atof(v) > 20.0) die("The height of the BS must be between 10m and 20m.");
+            base.hBS = (float)atof(v);
+        } else if (is(a, "--hut", "-ut", "-u")) {
+            if (atof(v) < 1.5 || atof(v) > 22.5) die("The height of the UE must be between 1.5m and 22.5m.");
+            base.hUT = (float)atof(v);
+        } else if (strcmp(a, "--program") == 0) {
+            /* handled above */
+        } else if (strcmp(a, "--rng") == 0) {
+            rng = strcmp(v, "philox") == 0 ? PRACH_RNG_PHILOX : PRACH_RNG_GLIBC;
+        } else if (strcmp(a, "--nue") == 0) {
+            if (atoi(v) < 1) die("Number of UEs must be greater than zero.");
+            sweep_lo = sweep_hi = atoi(v); sweep_step = 1;
+        } else if (strcmp(a, "--sweep") == 0) {
+            if (sscanf(v, "%d:%d:%d", &sweep_lo, &sweep_hi, &sweep_step) != 3 || sweep_lo < 1 || sweep_step < 1 || sweep_hi < sweep_lo)
+                die("--sweep LO:HI:STEP");
+        } else if (strcmp(a, "--out") == 0) {
+            outdir = v;
+        } else if (strcmp(a, "--logs") == 0) {
+            want_logs = atoi(v) != 0;
+        } else if (strcmp(a, "--device") == 0) {
+            device = atoi(v);
+        } else {
+            usage_and_exit();
+        }
+    }
+    base.rng_mode = rng;
+
+    if (base.uniform) printf("Traffic model: Uniform\n\n"); /* WithNOMA:208-213 */
+    else printf("Traffic model: Beta\n\n");
+
+    prach_engine *eng = NULL;
+    int rc = prach_engine_create(device, &eng);
+    if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+
+    const int npts = (sweep_hi - sweep_lo) / sweep_step + 1;
+    prach_ue_log *logbuf = want_logs ? (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)sweep_hi) : NULL;
+    char text[4096];
+    for (int randomSeed = 0; randomSeed < randomMax; randomSeed++) { /* WithNOMA:216 */
+        struct timespec ts0, ts1;
+        clock_gettime(CLOCK_MONOTONIC, &ts0);
+        uint64_t offset = 0; /* one srand() per seed; the stream runs on across the sweep (WithNOMA:219-221) */
+        for (int k = 0; k < npts; k++) {
+            prach_cfg c = base;
+            c.nUE = sweep_lo + k * sweep_step;
+            c.seed = (uint64_t)randomSeed;
+            c.stream_offset = offset;
+            prach_result r;
+            prach_ue_log *lp = logbuf;
+            rc = prach_run_trials(eng, &c, 1, &r, want_logs ? &lp : NULL);
+            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+            offset += r.draws;
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
+            const double lat = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
+            prach_format_stdout(&c, &r, lat, text, sizeof text);
+            fputs(text, stdout);
+            rc = prach_write_trial_files(&c, &r, want_logs ? logbuf : NULL, lat, outdir);
+            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+        }
+    }
+    free(logbuf);
+    prach_engine_destroy(eng);
+    return 0;
+}

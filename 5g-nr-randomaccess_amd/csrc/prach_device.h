@@ -1,0 +1,72 @@
+// prach_device.h — device-side data layout shared by the kernels (prach_kernels.hip) and the
+// engine (prach_engine.hip).  gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/prach.h"
+
+namespace prach {
+
+// ---- per-UE hot record: ONE 16-byte word (a single global_load_dwordx4 per UE per subframe) -------
+//   x  txTime                       (Beta.c:15)   [PEND_RESET: the drawn backoff `tmp`, until applied]
+//   y  tb  timer base: the subframe at which `timer` was last zeroed (timer = executed - tb), or the
+//          final timer value once the UE has succeeded (Beta.c:13,378)
+//   z  bo  nowBackoff, stored as its expiry subframe when positive (value = max(bo - t, 0)), as the
+//          literal value when <= 0 (Beta.c:25)     [PEND_RESET: the UE's previous preamble]
+//   w  pk  packed small fields, see below
+// timer and nowBackoff are therefore never rewritten while a UE merely waits (timerIncrease,
+// Beta.c:413-419, costs no memory traffic).
+constexpr unsigned PK_ACT_SHIFT = 0, PK_CONN_SHIFT = 2, PK_PRE_SHIFT = 4, PK_RAR_SHIFT = 12, PK_MRC_SHIFT = 20,
+                   PK_PEND_SHIFT = 28;
+constexpr int ACT_IDLE = 0; // active == -1 (not yet arrived)
+constexpr int ACT_DONE = 1; // active ==  0 (msg4Flag == 1)
+constexpr int ACT_M1 = 2;   // active ==  1 (Msg1/Msg2 phase)
+constexpr int ACT_M3 = 3;   // active ==  2 (Msg3/Msg4 phase)
+
+// what the deferred "apply" of the previous subframe still owes this UE
+constexpr int PEND_NONE = 0, PEND_STAY = 1, PEND_CALLER = 2, PEND_RESET = 3, PEND_PASSIVE = 4, PEND_RJOIN = 5,
+              PEND_GRANTED = 6;
+// ordered "special" events handed to the resolver
+constexpr int EV_CALLER = 1, EV_RESETCAND = 2, EV_PASSIVE = 3, EV_RJOIN = 4;
+
+struct alignas(16) Event {
+    int idx;  // UE index
+    int info; // type | bucket p << 8 | old bucket q << 16
+    int le;   // #pre-members of bucket p with index <= idx
+    int pad;
+};
+
+struct DevResult {
+    int status, time_exit, nSuccess, collisionPreambles, totalPreambleTxop, activeCheck, continueFailed,
+        finalSuccess, ptcSum, fcSum;
+    unsigned long long draws, steps;
+    long long sumTimer;
+    unsigned long long dbg[4];
+};
+
+struct TrialDev {
+    int variant, uniform, nUE, nP, backoff, nGrantUL, maxRarWindow, maxMsg2, aT, rng_mode, maxTime, stop;
+    unsigned seed_lo, seed_hi;
+    unsigned long long stream_len;
+    int4 *rec;
+    int *ptc, *ftt, *stt, *fcnt; // cold per-UE fields: preambleTxCounter, firstTxTime, secondTxTime, failCount
+    unsigned *nd;                // philox: per-UE draw index
+    Event *evbuf, *evbuf2;       // event scratch (per-wave segments / compacted)
+    int *sidx;                   // singleton-caller scratch
+    const int *sched;            // arrival schedule (activeCheck per access slot)
+    const int *stream;           // glibc mode: draw stream window
+    prach_ue_log *logs;          // nullable
+    int *timers;                 // per UE: final timer if succeeded, else INT_MIN
+    DevResult *out;
+};
+
+constexpr int WG_THREADS = 1024;
+constexpr int NW = WG_THREADS / 64; // waves per workgroup
+constexpr int EVCAP = 1024;         // events staged in LDS (more: resolved from global scratch)
+constexpr int SCAP = 1024;          // singleton callers staged in LDS
+constexpr int RCCAP = 256;          // reset-cycle re-join candidates per subframe
+
+size_t trial_kernel_lds_bytes(int nP);
+hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream);
+
+} // namespace prach

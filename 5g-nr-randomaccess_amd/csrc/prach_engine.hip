@@ -1,0 +1,281 @@
+// prach_engine.hip — host side of libprach_hip.so: the engine behind the C ABI in include/prach.h.
+// Owns the HIP stream, one device arena (grown on demand, never allocated per subframe), stages
+// the per-trial parameter blocks / arrival tables / draw streams, launches the trial kernel and
+// turns DevResult into prach_result.  There is NO CPU fallback: without a gfx950 device every
+// entry point that simulates returns PRACH_ERR_DEVICE.
+#include "prach_device.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <limits.h>
+#include <vector>
+
+using namespace prach;
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            std::fprintf(stderr, "[prach] HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, \
+                         __LINE__, hipGetErrorString(e_));                                            \
+            return PRACH_ERR_DEVICE;                                                                  \
+        }                                                                                             \
+    } while (0)
+
+struct prach_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char *arena = nullptr;
+    size_t arena_cap = 0;
+    prach_timing last{};
+    int64_t opt_stream_factor = 0; // glibc: initial draws-per-UE budget override (0 = auto)
+};
+
+namespace {
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct TrialLayout {
+    size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, end;
+    size_t stream_len, sched_len;
+};
+
+TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t stream_len) {
+    TrialLayout L{};
+    size_t o = base;
+    const size_t n = (size_t)c.nUE;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.rec = take(16 * n);
+    L.ptc = take(4 * n); L.ftt = take(4 * n); L.stt = take(4 * n); L.fcnt = take(4 * n); L.nd = take(4 * n);
+    L.evbuf = take(sizeof(Event) * n); L.evbuf2 = take(sizeof(Event) * n);
+    L.sidx = take(4 * (n + 256));
+    L.sched_len = (size_t)(prach_max_time(&c) / c.accessTime + 2);
+    L.sched = take(4 * L.sched_len);
+    L.stream_len = stream_len;
+    L.stream = take(4 * (stream_len + 2));
+    L.logs = want_logs ? take(sizeof(prach_ue_log) * n) : 0;
+    L.timers = take(4 * n);
+    L.out = take(sizeof(DevResult));
+    L.end = o;
+    return L;
+}
+
+// initial glibc stream budget (draws) for a trial; the kernel reports exhaustion and we retry bigger
+uint64_t stream_budget(const prach_cfg &c, int attempt, int64_t factor) {
+    uint64_t per = factor > 0 ? (uint64_t)factor : 450; // 100k UEs / 12 grants / backoff 20 consume ~325 per UE
+    uint64_t b = (uint64_t)c.nUE * per + (1u << 20);
+    return b << (2 * attempt);
+}
+
+} // namespace
+
+extern "C" {
+
+int prach_engine_create(int device, prach_engine **out) {
+    if (!out) return PRACH_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "[prach] no HIP device: libprach_hip needs an MI355X (gfx950); there is no CPU fallback\n");
+        return PRACH_ERR_DEVICE;
+    }
+    if (device < 0 || device >= ndev) return PRACH_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "[prach] device %d is %s; this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return PRACH_ERR_DEVICE;
+    }
+    prach_engine *e = new prach_engine();
+    e->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&e->ev0));
+    HIPCHK(hipEventCreate(&e->ev1));
+    *out = e;
+    return PRACH_OK;
+}
+
+void prach_engine_destroy(prach_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->arena) hipFree(e->arena);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
+    if (!e || !key) return PRACH_ERR_ARG;
+    if (std::strcmp(key, "stream_factor") == 0) { e->opt_stream_factor = value; return PRACH_OK; }
+    return PRACH_ERR_ARG;
+}
+
+int prach_last_timing(const prach_engine *e, prach_timing *out) {
+    if (!e || !out) return PRACH_ERR_ARG;
+    *out = e->last;
+    return PRACH_OK;
+}
+
+// one launch over the trials idx[0..m) (all the same rng_mode); attempt = glibc stream retry level
+static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, prach_result *results,
+                     prach_ue_log *const *ue_logs, int attempt, double &kernel_ms, double &upload_ms) {
+    const int rng_mode = cfgs[idx[0]].rng_mode;
+    std::vector<TrialLayout> lay(m);
+    size_t o = align_up(sizeof(TrialDev) * (size_t)m, 256);
+    int maxP = 1;
+    for (int k = 0; k < m; k++) {
+        const prach_cfg &c = cfgs[idx[k]];
+        const bool wl = ue_logs && ue_logs[idx[k]];
+        const size_t sl = rng_mode == PRACH_RNG_GLIBC ? (size_t)stream_budget(c, attempt, e->opt_stream_factor) : 0;
+        lay[k] = layout_trial(c, o, wl, sl);
+        o = lay[k].end;
+        if (c.nPreamble > maxP) maxP = c.nPreamble;
+    }
+    if (o > e->arena_cap) {
+        if (e->arena) HIPCHK(hipFree(e->arena));
+        e->arena = nullptr;
+        e->arena_cap = 0;
+        const size_t want = o + (o >> 3);
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->arena), want));
+        e->arena_cap = want;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<TrialDev> td(m);
+    std::vector<int32_t> sched;
+    std::vector<int32_t> strm;
+    std::vector<int32_t> nAccess(m, 0);
+    for (int k = 0; k < m; k++) {
+        const prach_cfg &c = cfgs[idx[k]];
+        const TrialLayout &L = lay[k];
+        TrialDev &d = td[k];
+        d.variant = c.variant; d.uniform = c.uniform; d.nUE = c.nUE; d.nP = c.nPreamble; d.backoff = c.backoff;
+        d.nGrantUL = c.nGrantUL; d.maxRarWindow = c.maxRarWindow; d.maxMsg2 = c.maxMsg2TxCount; d.aT = c.accessTime;
+        d.rng_mode = c.rng_mode; d.maxTime = prach_max_time(&c);
+        d.stop = (c.max_steps > 0 && c.max_steps < d.maxTime) ? c.max_steps : d.maxTime;
+        d.seed_lo = (unsigned)c.seed; d.seed_hi = (unsigned)(c.seed >> 32);
+        d.stream_len = L.stream_len;
+        char *A = e->arena;
+        d.rec = reinterpret_cast<int4 *>(A + L.rec);
+        d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);
+        d.stt = reinterpret_cast<int *>(A + L.stt); d.fcnt = reinterpret_cast<int *>(A + L.fcnt);
+        d.nd = reinterpret_cast<unsigned *>(A + L.nd);
+        d.evbuf = reinterpret_cast<Event *>(A + L.evbuf); d.evbuf2 = reinterpret_cast<Event *>(A + L.evbuf2);
+        d.sidx = reinterpret_cast<int *>(A + L.sidx);
+        d.sched = reinterpret_cast<const int *>(A + L.sched);
+        d.stream = reinterpret_cast<const int *>(A + L.stream);
+        d.logs = L.logs ? reinterpret_cast<prach_ue_log *>(A + L.logs) : nullptr;
+        d.timers = reinterpret_cast<int *>(A + L.timers);
+        d.out = reinterpret_cast<DevResult *>(A + L.out);
+        sched.assign(L.sched_len, c.nUE);
+        prach_arrival_schedule(&c, sched.data(), (int)L.sched_len, &nAccess[k]);
+        HIPCHK(hipMemcpyAsync(A + L.sched, sched.data(), 4 * L.sched_len, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream)); // staging vector is reused
+        if (rng_mode == PRACH_RNG_GLIBC) {
+            strm.resize(L.stream_len);
+            prach_glibc_stream((uint32_t)c.seed, c.stream_offset, L.stream_len, strm.data());
+            HIPCHK(hipMemcpyAsync(A + L.stream, strm.data(), 4 * L.stream_len, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(e->arena, td.data(), sizeof(TrialDev) * (size_t)m, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    auto t1 = std::chrono::steady_clock::now();
+    upload_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    kernel_ms += ms;
+    e->last.launches++;
+    e->last.workgroups = m;
+
+    std::vector<int32_t> timers;
+    for (int k = 0; k < m; k++) {
+        const prach_cfg &c = cfgs[idx[k]];
+        const TrialLayout &L = lay[k];
+        DevResult dr;
+        HIPCHK(hipMemcpy(&dr, e->arena + L.out, sizeof(dr), hipMemcpyDeviceToHost));
+        prach_result &r = results[idx[k]];
+        std::memset(&r, 0, sizeof(r));
+        r.status = dr.status;
+        r.time_exit = dr.time_exit;
+        r.maxTime = prach_max_time(&c);
+        r.nSuccessUE = dr.nSuccess;
+        r.failedUEs = c.nUE - dr.nSuccess;
+        r.preambleTxCount = dr.ptcSum;
+        r.failCounts = dr.fcSum;
+        r.collisionPreambles = dr.collisionPreambles;
+        r.totalPreambleTxop = dr.totalPreambleTxop;
+        r.activeCheck = dr.activeCheck;
+        r.nAccessUE = nAccess[k];
+        r.continueFaliedUEs = dr.continueFailed;
+        r.finalSuccessUEs = dr.finalSuccess;
+        r.sumTimer = dr.sumTimer;
+        r.draws = dr.draws;
+        r.steps = dr.steps;
+        if (dr.status != PRACH_OK) continue;
+        // totalDelay is a FLOAT running sum in index order (Beta.c:186,193): exact in integer
+        // arithmetic while it stays below 2^24, otherwise replay the float additions on the host.
+        if (dr.sumTimer < (1ll << 24)) {
+            r.totalDelay = (float)dr.sumTimer;
+        } else {
+            timers.resize((size_t)c.nUE);
+            HIPCHK(hipMemcpy(timers.data(), e->arena + L.timers, 4 * (size_t)c.nUE, hipMemcpyDeviceToHost));
+            float td_ = 0;
+            for (int i = 0; i < c.nUE; i++)
+                if (timers[i] != INT_MIN) td_ += (float)timers[i];
+            r.totalDelay = td_;
+        }
+        if (L.logs)
+            HIPCHK(hipMemcpy(ue_logs[idx[k]], e->arena + L.logs, sizeof(prach_ue_log) * (size_t)c.nUE, hipMemcpyDeviceToHost));
+    }
+    return PRACH_OK;
+}
+
+int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result *results, prach_ue_log *const *ue_logs) {
+    if (!e || !cfgs || !results || n <= 0) return PRACH_ERR_ARG;
+    for (int k = 0; k < n; k++) {
+        int v = prach_cfg_validate(&cfgs[k]);
+        if (v != PRACH_OK) return v;
+        if (cfgs[k].variant == PRACH_VARIANT_NOMA_C) return PRACH_ERR_UNSUPPORTED;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    auto t0 = std::chrono::steady_clock::now();
+    e->last = prach_timing{};
+    double kernel_ms = 0, upload_ms = 0;
+    for (int mode = 0; mode < 2; mode++) {
+        std::vector<int> idx;
+        for (int k = 0; k < n; k++)
+            if (cfgs[k].rng_mode == mode) idx.push_back(k);
+        int attempt = 0;
+        while (!idx.empty()) {
+            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, attempt, kernel_ms, upload_ms);
+            if (rc != PRACH_OK) return rc;
+            std::vector<int> again; // glibc trials whose draw-stream window ran out: rerun with a larger one
+            for (int k : idx)
+                if (results[k].status == PRACH_ERR_STREAM) again.push_back(k);
+            idx.swap(again);
+            if (++attempt > 6) return PRACH_ERR_STREAM;
+        }
+    }
+    uint64_t upd = 0;
+    int worst = PRACH_OK;
+    for (int k = 0; k < n; k++) {
+        upd += (uint64_t)cfgs[k].nUE * results[k].steps;
+        if (results[k].status != PRACH_OK) worst = results[k].status;
+    }
+    e->last.kernel_ms = kernel_ms;
+    e->last.upload_ms = upload_ms;
+    e->last.updates = upd;
+    e->last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return worst;
+}
+
+} // extern "C"

@@ -1,0 +1,242 @@
+/* prach_host.c — host-side half of the C ABI that needs no device: parameter defaults and
+ * validation, the deterministic arrival schedule, the glibc rand() stream, and the reference's
+ * text surfaces (stdout block, Results.txt, Logs.txt).  Plain C like the reference.
+ *
+ * Reference lines are cited per function; nothing here is copied from the reference — the
+ * formats are reproduced because the drop-in boundary of this project IS those files
+ * (SURVEY.md §8b).
+ */
+#define _GNU_SOURCE
+#include "../../include/prach.h"
+
+#include <errno.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+/* Beta.c:47-57 (BETA_C) / WithNOMA:70-88 (WITHNOMA_C): the hard-coded / default parameters */
+void prach_cfg_defaults(prach_cfg *c, int variant) {
+    memset(c, 0, sizeof(*c));
+    c->variant = variant;
+    c->uniform = 0;
+    c->nUE = 100000;
+    c->nPreamble = 54;
+    c->backoff = 20;
+    c->nGrantUL = variant == PRACH_VARIANT_BETA_C ? 54 : 12;
+    c->maxRarWindow = 6;
+    c->maxMsg2TxCount = 9;
+    c->accessTime = 5;
+    c->rng_mode = PRACH_RNG_GLIBC;
+    c->seed = 0;
+    c->stream_offset = 0;
+    c->cellRadius = 400.0f;
+    c->hBS = 10.0f;
+    c->hUT = 1.8f;
+}
+
+int prach_cfg_validate(const prach_cfg *c) {
+    if (!c) return PRACH_ERR_ARG;
+    if (c->variant != PRACH_VARIANT_BETA_C && c->variant != PRACH_VARIANT_WITHNOMA_C && c->variant != PRACH_VARIANT_NOMA_C)
+        return PRACH_ERR_ARG;
+    if (c->nUE < 1 || c->nPreamble < 1 || c->backoff < 1 || c->nGrantUL < 1 || c->accessTime < 1) return PRACH_ERR_ARG;
+    if (c->maxRarWindow < 1 || c->maxMsg2TxCount < 0 || c->max_steps < 0) return PRACH_ERR_ARG;
+    if (c->rng_mode != PRACH_RNG_GLIBC && c->rng_mode != PRACH_RNG_PHILOX) return PRACH_ERR_ARG;
+    if (c->nPreamble > 254 || c->maxRarWindow > 255 || c->maxMsg2TxCount > 255) return PRACH_ERR_UNSUPPORTED;
+    if (c->nUE > (1 << 24)) return PRACH_ERR_UNSUPPORTED;
+    return PRACH_OK;
+}
+
+int prach_max_time(const prach_cfg *c) { return c->uniform ? 60000 : 10000; } /* Beta.c:92,103 */
+
+const char *prach_strerror(int s) {
+    switch (s) {
+    case PRACH_OK: return "ok";
+    case PRACH_ERR_ARG: return "invalid argument";
+    case PRACH_ERR_UNSUPPORTED: return "parameter outside the supported range (nPreamble<=254, maxRarWindow<=255, maxMsg2TxCount<=255)";
+    case PRACH_ERR_DEVICE: return "HIP device/runtime error (an MI355X/gfx950 device is required; there is no CPU fallback)";
+    case PRACH_ERR_STREAM: return "glibc draw stream exhausted";
+    case PRACH_ERR_INTERNAL: return "device-side consistency check failed";
+    case PRACH_ERR_IO: return "I/O error";
+    default: return "unknown status";
+    }
+}
+
+/* Arrival process.  Beta: every accessTime ms, activeCheck += ceil(nUE * pdf(t/maxTime) / (maxTime/accessTime))
+ * with the reference's mixed float/double evaluation (Beta.c:127-128, beta_dist Beta.c:516-519:
+ * the normaliser is the literal 0.0165, `1 - x` is a float subtraction, pow() runs in double, the
+ * product is rounded to float on return).  Uniform: += ceil(n*accessTime/60000), min 1 (Beta.c:95-100).
+ * The process uses no random numbers, so it is a table. */
+static float beta34_density(float x) {
+    const float a = 3, b = 4;
+    float v = (1 / 0.0165) * (pow(x, (a - 1))) * (pow((1 - x), (b - 1)));
+    return v;
+}
+
+int prach_arrival_schedule(const prach_cfg *c, int32_t *out, int cap, int32_t *nAccessUEo) {
+    const int nUE = c->nUE, aT = c->accessTime, maxTime = prach_max_time(c);
+    int nAccessUE = 0;
+    if (c->uniform) {
+        nAccessUE = ceil((float)nUE * (float)aT * 1.0 / (float)maxTime);
+        if (nAccessUE <= 0) nAccessUE = 1;
+    }
+    if (nAccessUEo) *nAccessUEo = nAccessUE;
+    int activeCheck = 0, s = 0;
+    for (int time = 0; time < maxTime; time += aT, s++) {
+        if (activeCheck < nUE) {
+            if (c->uniform) {
+                activeCheck += nAccessUE;
+            } else {
+                float pdf = beta34_density((float)time / (float)maxTime);
+                activeCheck += (int)ceil((float)nUE * pdf / ((float)maxTime / (float)aT));
+            }
+            if (activeCheck >= nUE) activeCheck = nUE;
+        }
+        if (s < cap) out[s] = activeCheck;
+    }
+    return s;
+}
+
+/* glibc srand()/rand() (stdlib/random_r.c, TYPE_3: degree 31, separation 3, 310 warm-up draws).
+ * The reference links libc's rand(); reproducing its exact stream is what makes per-trial counts
+ * bit-exact "under identical seeds".  Checked against libc itself in tests/test_host_logic.py. */
+void prach_glibc_stream(uint32_t seed, uint64_t first, uint64_t n, int32_t *out) {
+    uint32_t r[31];
+    int32_t word = (int32_t)(seed == 0 ? 1u : seed);
+    r[0] = (uint32_t)word;
+    for (int i = 1; i < 31; i++) {
+        int32_t hi = word / 127773, lo = word % 127773;
+        word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        r[i] = (uint32_t)word;
+    }
+    int f = 3, b = 0;
+    const uint64_t skip = 310 + first;
+    for (uint64_t k = 0; k < skip + n; k++) {
+        r[f] += r[b];
+        if (k >= skip) out[k - skip] = (int32_t)(r[f] >> 1);
+        if (++f == 31) f = 0;
+        if (++b == 31) b = 0;
+    }
+}
+
+/* ---- text surfaces ---------------------------------------------------------------------------- */
+
+size_t prach_format_logs(const prach_ue_log *ue, int nUE, char *buf, size_t cap) {
+    size_t off = 0;
+    char line[512];
+    for (int i = 0; i < nUE; i++) {
+        const prach_ue_log *u = ue + i;
+        int n = snprintf(line, sizeof line,
+                         "Idx: %d | Timer: %d | Active: %d | txTime: %d | FirstTxTime: %d | SecondTxTime: %d | "
+                         "NowBackoff: %d | Preamble: %d | Preamble change: %d | RAR window: %d | Max RAR: %d | "
+                         "Preamble reTx: %d | MSG 2 Flag: %d | ConnectRequest: %d | MSG 4 Flag: %d\n",
+                         u->idx, u->timer, u->active, u->txTime, u->firstTxTime, u->secondTxTime, u->nowBackoff,
+                         u->preamble, u->preambleChange, u->rarWindow, u->maxRarCounter, u->preambleTxCounter,
+                         u->msg2Flag, u->connectionRequest, u->msg4Flag);
+        if (buf && off + (size_t)n <= cap) memcpy(buf + off, line, (size_t)n);
+        off += (size_t)n;
+    }
+    return off;
+}
+
+typedef struct { float ratioSuccess, nCollisionPreambles, averagePreambleTx, averageDelay; } derived_t;
+
+/* the float arithmetic of saveSimulationLog (Beta.c:434-438) */
+static derived_t derive(const prach_cfg *c, const prach_result *r) {
+    derived_t d;
+    d.ratioSuccess = (float)r->nSuccessUE / (float)c->nUE * 100.0;
+    d.nCollisionPreambles = (float)r->collisionPreambles / ((float)c->nUE * (float)c->nPreamble);
+    d.averagePreambleTx = (float)r->preambleTxCount / (float)r->nSuccessUE;
+    d.averageDelay = r->totalDelay / (float)r->nSuccessUE;
+    return d;
+}
+
+size_t prach_format_results(const prach_cfg *c, const prach_result *r, double latency_s, char *buf, size_t cap) {
+    derived_t d = derive(c, r);
+    char tmp[1024];
+    int n;
+    if (c->variant == PRACH_VARIANT_WITHNOMA_C)
+        n = snprintf(tmp, sizeof tmp,
+                     "%d\n%.2lf\n%d\n%.2lf\n%.2lf\nNumber of total preamble tx: %d\nFinally Falied: %d\nFinally Success: %lf\n",
+                     c->nUE, d.ratioSuccess, r->nSuccessUE, d.averagePreambleTx, d.averageDelay, r->preambleTxCount,
+                     r->continueFaliedUEs,
+                     (float)r->finalSuccessUEs / (float)(r->continueFaliedUEs + r->finalSuccessUEs));
+    else
+        n = snprintf(tmp, sizeof tmp, "%d\n%.2lf\n%d\n%.2lf\n%.2lf\n%lf", c->nUE, d.ratioSuccess, r->nSuccessUE,
+                     d.averagePreambleTx, d.averageDelay, latency_s);
+    if (buf && (size_t)n < cap) memcpy(buf, tmp, (size_t)n + 1);
+    return (size_t)n;
+}
+
+size_t prach_format_stdout(const prach_cfg *c, const prach_result *r, double latency_s, char *buf, size_t cap) {
+    derived_t d = derive(c, r);
+    char tmp[2048];
+    int n = snprintf(tmp, sizeof tmp, "-------- %05d Result ---------\n", r->activeCheck);
+    if (c->uniform) n += snprintf(tmp + n, sizeof tmp - n, "Number of RA try UEs per Subframe: %d\n", r->nAccessUE);
+    if (c->variant == PRACH_VARIANT_WITHNOMA_C) n += snprintf(tmp + n, sizeof tmp - n, "Fail Counts: %d\n", r->failCounts);
+    else n += snprintf(tmp + n, sizeof tmp - n, "Latency: %lf\n", latency_s);
+    n += snprintf(tmp + n, sizeof tmp - n,
+                  "Number of UEs: %d\nTotal simulation time: %dms\nSuccess ratio: %.2lf\nNumber of succeed UEs: %d\n", c->nUE,
+                  r->time_exit, d.ratioSuccess, r->nSuccessUE);
+    if (c->variant == PRACH_VARIANT_WITHNOMA_C)
+        n += snprintf(tmp + n, sizeof tmp - n, "Number of falied UEs: %d\n", r->continueFaliedUEs);
+    n += snprintf(tmp + n, sizeof tmp - n,
+                  "Number of collision preambles: %.6lf\nAverage preamble tx count: %.2lf\nAverage delay: %.2lf\n",
+                  d.nCollisionPreambles, d.averagePreambleTx, d.averageDelay);
+    if (buf && (size_t)n < cap) memcpy(buf, tmp, (size_t)n + 1);
+    return (size_t)n;
+}
+
+/* Output file names: Beta.c:452-456,490-494 and WithNOMA:754-758,801-805 (note Beta.c's Uniform log
+ * name has no seed in it). */
+int prach_result_file_name(const prach_cfg *c, int is_log, char *buf, size_t cap) {
+    const int seed = (int)c->seed;
+    int n;
+    if (c->variant == PRACH_VARIANT_WITHNOMA_C) {
+        const char *dir = c->uniform ? "NomaUniformResults" : "NomaBetaResults";
+        n = is_log ? snprintf(buf, cap, "%s/%d_%d_UE%05d_Logs.txt", dir, seed, c->nPreamble, c->nUE)
+                   : snprintf(buf, cap, "%s/%d_%d_%d_Results.txt", dir, seed, c->nPreamble, c->nUE);
+    } else {
+        const char *dir = c->uniform ? "BasicUniformSimulationResults" : "BasicBetaSimulationResults";
+        if (!is_log) n = snprintf(buf, cap, "%s/%d_%d_%d_Results.txt", dir, seed, c->nPreamble, c->nUE);
+        else if (c->uniform) n = snprintf(buf, cap, "%s/%d_Exclude_msg2_failures_UE%05d_Logs.txt", dir, c->nPreamble, c->nUE);
+        else n = snprintf(buf, cap, "%s/%d_%d_UE%05d_Logs.txt", dir, seed, c->nPreamble, c->nUE);
+    }
+    return (n > 0 && (size_t)n < cap) ? PRACH_OK : PRACH_ERR_ARG;
+}
+
+static int write_all(const char *path, const char *data, size_t n) {
+    FILE *fp = fopen(path, "w+");
+    if (!fp) return PRACH_ERR_IO;
+    size_t w = fwrite(data, 1, n, fp);
+    if (fclose(fp) != 0 || w != n) return PRACH_ERR_IO;
+    return PRACH_OK;
+}
+
+int prach_write_trial_files(const prach_cfg *c, const prach_result *r, const prach_ue_log *ue, double latency_s,
+                            const char *root_dir) {
+    char rel[512], path[1024], dirp[1024];
+    const char *root = (root_dir && *root_dir) ? root_dir : ".";
+    int rc = prach_result_file_name(c, 0, rel, sizeof rel);
+    if (rc) return rc;
+    /* the reference mkdir()s its output directories (WithNOMA:67-68); Beta.c expects them to exist */
+    snprintf(dirp, sizeof dirp, "%s/%.*s", root, (int)(strchr(rel, '/') - rel), rel);
+    if (mkdir(dirp, 0755) != 0 && errno != EEXIST) return PRACH_ERR_IO;
+    char text[1024];
+    size_t n = prach_format_results(c, r, latency_s, text, sizeof text);
+    snprintf(path, sizeof path, "%s/%s", root, rel);
+    if ((rc = write_all(path, text, n)) != 0) return rc;
+    if (ue) {
+        size_t need = prach_format_logs(ue, c->nUE, NULL, 0);
+        char *buf = (char *)malloc(need + 1);
+        if (!buf) return PRACH_ERR_IO;
+        prach_format_logs(ue, c->nUE, buf, need + 1);
+        prach_result_file_name(c, 1, rel, sizeof rel);
+        snprintf(path, sizeof path, "%s/%s", root, rel);
+        rc = write_all(path, buf, need);
+        free(buf);
+    }
+    return rc;
+}

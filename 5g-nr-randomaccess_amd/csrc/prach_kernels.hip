@@ -1,0 +1,618 @@
+// prach_kernels.hip — hand-written HIP for gfx950 (MI355X / CDNA4): the per-subframe PRACH
+// random-access loop of RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351.
+//
+// One 1024-thread workgroup (16 wave64) simulates one (seed, nUE) trial; a batch of trials is a grid
+// of workgroups.  UE state is struct-of-arrays with ONE 16-byte hot record per UE (prach_device.h),
+// read with one coalesced global_load_dwordx4 per lane per subframe; timer and backoff counters are
+// stored as bases so waiting UEs are never rewritten.
+//
+// The reference runs the UE loop in index order with immediate side effects (preambleCollision
+// bumps every matched UE, Beta.c:353-358; grants go to callers in index order, Beta.c:336-347).
+// That order is reproduced EXACTLY, in parallel, by the decomposition validated on the CPU in
+// oracle/phase_model.c:
+//   pass      each wave owns a contiguous index range; per UE: deferred apply of the previous
+//             subframe's outcome, activation (Beta.c:136-146), selectPreamble (Beta.c:229-312),
+//             requestResourceAllocation (Beta.c:371-411) on its own state; per-wave LDS histogram of
+//             "pre-members" per preamble bucket (the UEs a preambleCollision scan would match), the
+//             lowest-index would-be caller per bucket, and an index-ordered list of special events
+//             (late joiners etc.), ranked with wavefront ballots;
+//   resolve   prefix over waves, first caller / check (= scan count) per call, singleton callers
+//             ranked by index for the RAR grants of the 5 ms window, collision counters;
+//   apply     folded into the next subframe's pass (txTime bumps, Msg2 success).
+// RNG: Philox4x32-10 per (UE, draw#) lane-locally, or the reference's own glibc rand() stream
+// addressed through an index-ordered prefix sum of per-UE draw counts (bit-exact vs the reference).
+#include "prach_device.h"
+#include <limits.h>
+
+namespace prach {
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int slot_align(int sub, int aT) { // Beta.c:268-277
+    const int m = sub % aT;
+    return m == 0 ? sub + 1 : (m == 1 ? sub : sub + (aT - m + 1));
+}
+__device__ __forceinline__ int now_backoff(int bo, int t) { return bo > 0 ? max(bo - t, 0) : bo; }
+__device__ __forceinline__ int enc_backoff(int X, int t) { return X > 0 ? t + X : X; }
+
+__device__ __forceinline__ int philox_draw31(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2,
+                                             unsigned c3) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (int)(c0 >> 1);
+}
+
+__device__ __forceinline__ unsigned long long lanemask_le(int lane) {
+    return lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+}
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// LDS carve-up (dynamic shared memory, 16-byte aligned base; prach_device.h sizes)
+struct Lds {
+    Event *evl;    // [EVCAP]
+    int *sidx;     // [SCAP]
+    int *rclist;   // [RCCAP]
+    int *scal;     // [64] scalars, see S_*
+    int *evcnt;    // [NW]
+    int *evoff;    // [NW+1]
+    unsigned *wdraws; // [NW]
+    int *wavehist; // [NW*nP]  per-wave pre-member histogram (then: exclusive prefix over waves)
+    int *smidx;    // [NW*nP]  per-wave lowest-index STAY pre-member per bucket
+    int *smle;     // [NW*nP]  its inclusive rank among the wave's pre-members of the bucket
+    int *total;    // [nP]
+    int *gsm;      // [nP] global lowest-index STAY pre-member
+    int *gsmle;    // [nP]
+    int *fcall;    // [nP] index of the first caller on the bucket this subframe (INT_MAX: none)
+    int *lcall;    // [nP] index of the last caller (-1: none)
+};
+enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_FINS, S_NS, S_NRC, S_NPOST, S_STATUS, S_PTC, S_FC, S_ND_LO,
+       S_SUMT_LO = 16 /* 64-bit at [16,17] */, S_ND64 = 18 /* 64-bit at [18,19] */ };
+
+__device__ __forceinline__ Lds carve(char *smem, int nP) {
+    Lds L;
+    L.evl = reinterpret_cast<Event *>(smem);
+    int *ip = reinterpret_cast<int *>(smem + sizeof(Event) * EVCAP);
+    L.sidx = ip; ip += SCAP;
+    L.rclist = ip; ip += RCCAP;
+    L.scal = ip; ip += 64;
+    L.evcnt = ip; ip += NW;
+    L.evoff = ip; ip += NW + 16;
+    L.wdraws = reinterpret_cast<unsigned *>(ip); ip += NW;
+    L.wavehist = ip; ip += NW * nP;
+    L.smidx = ip; ip += NW * nP;
+    L.smle = ip; ip += NW * nP;
+    L.total = ip; ip += nP;
+    L.gsm = ip; ip += nP;
+    L.gsmle = ip; ip += nP;
+    L.fcall = ip; ip += nP;
+    L.lcall = ip; ip += nP;
+    return L;
+}
+size_t trial_kernel_lds_bytes(int nP) {
+    return sizeof(Event) * EVCAP + sizeof(int) * (SCAP + RCCAP + 64 + NW + NW + 16 + NW + 3 * NW * nP + 5 * nP);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one pass over the UEs [0, activeCheck); MODE: 0 fused (apply + activate + select)  [philox]
+//                                                1 apply + activate + count draws     [glibc]
+//                                                2 select only                        [glibc]
+//                                                3 apply only                         [final]
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool GLIBC>
+__device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const int t, const int prevAC,
+                                        const int activeCheck, const unsigned long long stepbase) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nP = P.nP, aT = P.aT;
+    const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
+    const int groups = (activeCheck + 63) >> 6;
+    const int gper = (groups + NW - 1) / NW;
+    const int g0 = w * gper, g1 = min(groups, g0 + gper);
+    int evn = 0;
+    unsigned wdraw = 0;
+    unsigned long long woff = 0;
+    if (MODE == 2 && GLIBC) {
+        woff = stepbase;
+        for (int k = 0; k < w; k++) woff += L.wdraws[k];
+    }
+    int c_succ = 0, c_contf = 0;
+    const int tp = t - 1;
+
+    for (int g = g0; g < g1; g++) {
+        const int i = g * 64 + lane;
+        const bool valid = i < activeCheck;
+        int4 r = make_int4(-1, 0, 0, 0);
+        if (valid) r = P.rec[i];
+        int tx = r.x, tb = r.y, bo = r.z;
+        int act = (r.w >> PK_ACT_SHIFT) & 3, conn = (r.w >> PK_CONN_SHIFT) & 3, pre = (r.w >> PK_PRE_SHIFT) & 0xff,
+            rar = (r.w >> PK_RAR_SHIFT) & 0xff, mrc = (r.w >> PK_MRC_SHIFT) & 0xff, pend = (r.w >> PK_PEND_SHIFT) & 7;
+        bool dirty = false;
+
+        if (MODE != 2) {
+            // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
+            if (pend != PEND_NONE) {
+                if (pend >= PEND_GRANTED) { // singleton caller that got an UL grant (Beta.c:338-343)
+                    act = ACT_M3; tx = tp + 11; conn = 0;
+                    if (pend > PEND_GRANTED) bo = 0;
+                } else if (pend == PEND_STAY || pend == PEND_CALLER) {
+                    tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
+                } else if (pend == PEND_RESET) {
+                    const int q = bo, tmp = tx;
+                    const int bumped = L.fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
+                    const int x = slot_align(tp + bumped + tmp, aT);
+                    if (x == tp) { bo = 0; tx = tp + 1; } // re-joined and called, no grant
+                    else { tx = x; bo = x; }
+                } else if (pend == PEND_PASSIVE) {
+                    if (L.fcall[pre - 1] != INT_MAX) tx = tp + 1;
+                } else { // PEND_RJOIN
+                    if (L.lcall[pre - 1] > i) tx = tp + 1;
+                }
+                pend = PEND_NONE;
+                dirty = true;
+            }
+            // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
+            if (MODE != 3 && valid && i >= prevAC) {
+                act = ACT_M1; tx = t + 1; tb = t;
+                P.ftt[i] = t + 1;
+                if (!GLIBC && withnoma) P.nd[i] = 2;
+                dirty = true;
+            }
+        }
+
+        // what this UE will do in subframe t, from its own state
+        const bool isM1 = act == ACT_M1;
+        const int nb = now_backoff(bo, t);
+        const bool firstsel = isM1 && pre == 0;
+        const bool contend = isM1 && pre != 0 && nb <= 0;
+        const bool expire = contend && (rar + 1 >= P.maxRarWindow);
+        const bool reset = expire && mrc >= P.maxMsg2;
+        const bool retx = expire && !reset;
+        const bool m3due = act == ACT_M3 && tx == t;
+        const bool m3first = m3due && conn == 0, m3to = m3due && conn != 0;
+        const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
+
+        if (MODE == 1) {
+            wdraw += (unsigned)need;
+            if (dirty) {
+                r.x = tx; r.y = tb; r.z = bo;
+                r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
+                      (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
+                P.rec[i] = r;
+            }
+            continue;
+        }
+        if (MODE == 3) {
+            if (dirty) {
+                r.x = tx; r.y = tb; r.z = bo;
+                r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
+                      (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
+                P.rec[i] = r;
+            }
+            continue;
+        }
+
+        // nothing to do for the whole wavefront?  (waiting / finished / not yet arrived UEs)
+        const bool busy = isM1 || m3due;
+        if (!__any(busy || dirty)) continue;
+
+        // ---- draws ----
+        int d1 = 0, d2 = 0;
+        if (__any(need > 0)) {
+            if (GLIBC) {
+                int x = need;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int y = __shfl_up(x, d);
+                    if (lane >= d) x += y;
+                }
+                const unsigned long long o = woff + (unsigned long long)(x - need);
+                if (need > 0) d1 = P.stream[o];
+                if (need > 1) d2 = P.stream[o + 1];
+                woff += (unsigned long long)__shfl(x, 63);
+            } else {
+                unsigned k = 0;
+                if (need > 0) k = P.nd[i];
+                d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)P.nUE, (unsigned)P.variant);
+                if (__any(need > 1))
+                    d2 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k + 1, (unsigned)P.nUE, (unsigned)P.variant);
+                if (need > 0) P.nd[i] = k + (unsigned)need;
+            }
+        }
+
+        // ---- selectPreamble / requestResourceAllocation on own state ----
+        const int oldp = pre - 1;
+        const bool member_pre = isM1 && tx == t && pre != 0; // matched by a preambleCollision scan right now
+        int evtype = 0, evp = 0, evq = 0;
+        if (firstsel) { // Beta.c:231-239
+            pre = d1 % nP + 1; rar = 0; mrc = 0; bo = 0;
+            P.ptc[i] = 1;
+            if (withnoma) P.fcnt[i] = 0;
+            if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = pre - 1; }
+            dirty = true;
+        } else if (isM1 && pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
+            if (member_pre) {
+                if (withnoma) pend = PEND_STAY; // WithNOMA:310 calls whatever nowBackoff is
+                else { pend = PEND_PASSIVE; evtype = EV_PASSIVE; evp = oldp; }
+                dirty = true;
+            }
+        } else if (contend) {
+            rar++; // Beta.c:245
+            dirty = true;
+            if (reset) { // Beta.c:250-281
+                if (withnoma) { c_contf++; P.fcnt[i] = P.fcnt[i] + 1; }
+                const int newp = d1 % nP;
+                const int tmp = d2 % P.backoff;
+                rar = 0; mrc = 0; tb = t;
+                P.ptc[i] = 1; P.ftt[i] = t + 1;
+                pre = newp + 1;
+                if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
+                    pend = PEND_RESET; tx = tmp; bo = oldp;
+                    if (tmp == 0 && aT > 1 && t % aT == 1) { evtype = EV_RESETCAND; evp = newp; evq = oldp; }
+                } else {
+                    tx = slot_align(tx + tmp, aT);
+                    bo = enc_backoff(tx - t, t);
+                    if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = newp; }
+                }
+            } else if (retx) { // Beta.c:282-308
+                rar = 0; mrc++;
+                P.ptc[i] = P.ptc[i] + 1;
+                const int tmp = d1 % P.backoff;
+                tx = slot_align(t + tmp, aT);
+                bo = enc_backoff(tx - t, t);
+                P.stt[i] = tx;
+                if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = oldp; } // the "late joiner"
+            } else if (member_pre) {
+                pend = PEND_STAY;
+            }
+        } else if (m3first) { // Beta.c:372-383
+            conn = 1;
+            const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
+            if ((double)pf > 0.1) { act = ACT_DONE; tb = (t - tb) + 6; c_succ++; }
+            else { conn = 2; tx += 48; }
+            dirty = true;
+        } else if (m3to) { // Msg3 timeout, Beta.c:384-410
+            c_contf++;
+            const int tmp = d1 % P.backoff;
+            tx = slot_align(tx + tmp, 5); // hard-coded accessTime = 5, Beta.c:389
+            act = ACT_M1;
+            bo = enc_backoff(tx - t, t);
+            pre = d2 % nP + 1;
+            tb = t; rar = 0; mrc = 0; conn = 0;
+            if (withnoma) P.fcnt[i] = P.fcnt[i] + 1;
+            if (tx == t) { pend = PEND_RJOIN; evtype = EV_RJOIN; evp = pre - 1; }
+            dirty = true;
+        }
+
+        // ---- bucket bookkeeping for the resolver (wavefront-level) ----
+        const bool stay = pend == PEND_STAY;
+        bool winner = false;
+        if (__any(stay)) {
+            if (stay) {
+                int *smp = &L.smidx[w * nP + oldp];
+                if (__atomic_load_n(smp, __ATOMIC_RELAXED) == INT_MAX) {
+                    atomicMin(smp, i);
+                    winner = __atomic_load_n(smp, __ATOMIC_RELAXED) == i;
+                }
+            }
+        }
+        const bool rankq = winner || evtype == EV_CALLER || evtype == EV_RESETCAND;
+        int le = 0;
+        {
+            unsigned long long qm = __ballot(rankq);
+            const int qp = winner ? oldp : evp;
+            while (qm) {
+                const int l = __ffsll((long long)qm) - 1;
+                qm &= qm - 1;
+                const int p = __shfl(qp, l);
+                const unsigned long long mm = __ballot(member_pre && oldp == p);
+                if (lane == l) le = L.wavehist[w * nP + p] + __popcll(mm & lanemask_le(lane));
+            }
+        }
+        if (member_pre) atomicAdd(&L.wavehist[w * nP + oldp], 1);
+        if (winner) L.smle[w * nP + oldp] = le;
+        {
+            const unsigned long long em = __ballot(evtype != 0);
+            if (em) {
+                if (evtype != 0) {
+                    Event e;
+                    e.idx = i; e.info = evtype | (evp << 8) | (evq << 16); e.le = le; e.pad = 0;
+                    P.evbuf[g0 * 64 + evn + __popcll(em & lanemask_lt(lane))] = e;
+                }
+                evn += __popcll(em);
+            }
+        }
+        if (dirty) {
+            r.x = tx; r.y = tb; r.z = bo;
+            r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
+                  (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
+            P.rec[i] = r;
+        }
+    }
+
+    if (MODE == 1) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) wdraw += __shfl_down(wdraw, d);
+        if (lane == 0) L.wdraws[w] = wdraw;
+    }
+    if (MODE == 0 || MODE == 2) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        if (lane == 0) {
+            L.evcnt[w] = evn;
+            if (c_succ) { atomicAdd(&L.scal[S_NSUCC], c_succ); atomicAdd(&L.scal[S_FINS], c_succ); }
+            if (c_contf) atomicAdd(&L.scal[S_CONTF], c_contf);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// resolve subframe t: who calls preambleCollision, with what scan count, who gets the RAR grants
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const int activeCheck, int &grantCheck) {
+    const int tid = threadIdx.x;
+    const int nP = P.nP;
+    const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
+    const int groups = (activeCheck + 63) >> 6;
+    const int gper = (groups + NW - 1) / NW;
+
+    __syncthreads(); // pass complete: wavehist / smidx / smle / evcnt / event segments are final
+    for (int p = tid; p < nP; p += WG_THREADS) {
+        int acc = 0, sm = INT_MAX, sle = 0;
+        for (int w = 0; w < NW; w++) {
+            const int s = L.smidx[w * nP + p];
+            if (sm == INT_MAX && s != INT_MAX) { sm = s; sle = acc + L.smle[w * nP + p]; }
+            const int h = L.wavehist[w * nP + p];
+            L.wavehist[w * nP + p] = acc;
+            acc += h;
+        }
+        L.total[p] = acc; L.gsm[p] = sm; L.gsmle[p] = sle; L.fcall[p] = sm; L.lcall[p] = -1;
+    }
+    if (tid <= NW) {
+        int s = 0;
+        for (int k = 0; k < tid; k++) s += L.evcnt[k];
+        L.evoff[tid] = s;
+    }
+    if (tid == 0) { L.scal[S_NS] = 0; L.scal[S_NRC] = 0; L.scal[S_NPOST] = 0; }
+    __syncthreads();
+
+    const int N = L.evoff[NW];
+    Event *const EVA = N <= EVCAP ? L.evl : P.evbuf2;
+    for (int k = tid; k < N; k += WG_THREADS) {
+        int w = 0;
+        while (w + 1 < NW && L.evoff[w + 1] <= k) w++;
+        Event e = P.evbuf[w * gper * 64 + (k - L.evoff[w])];
+        const int type = e.info & 0xff, p = (e.info >> 8) & 0xff;
+        e.le += L.wavehist[w * nP + p];
+        if (type == EV_CALLER) atomicMin(&L.fcall[p], e.idx);
+        else if (type == EV_RESETCAND) { const int s = atomicAdd(&L.scal[S_NRC], 1); if (s < RCCAP) L.rclist[s] = k; }
+        else atomicAdd(&L.scal[S_NPOST], 1);
+        EVA[k] = e;
+    }
+    __syncthreads();
+
+    // reset cycles that could land on this subframe: strictly in index order (rare, few)
+    const int nrc = L.scal[S_NRC];
+    if (nrc > 0) {
+        if (tid == 0) {
+            if (nrc > RCCAP) L.scal[S_STATUS] = PRACH_ERR_INTERNAL;
+            const int n = min(nrc, RCCAP);
+            for (int a = 1; a < n; a++) { // insertion sort: list position == index order
+                const int v = L.rclist[a];
+                int b = a - 1;
+                while (b >= 0 && L.rclist[b] > v) { L.rclist[b + 1] = L.rclist[b]; b--; }
+                L.rclist[b + 1] = v;
+            }
+            for (int a = 0; a < n; a++) {
+                Event e = EVA[L.rclist[a]];
+                const int p = (e.info >> 8) & 0xff, q = (e.info >> 16) & 0xff;
+                if (L.fcall[q] < e.idx) { e.info = 0; EVA[L.rclist[a]] = e; } // bumped before its turn
+                else if (e.idx < L.fcall[p]) L.fcall[p] = e.idx;
+            }
+        }
+        __syncthreads();
+    }
+
+    // every call: scan count `check` (Beta.c:321-330), counters (Beta.c:334,349-351 / WithNOMA:650-652)
+    const int npost = L.scal[S_NPOST];
+    int *const sing = (N + nP <= SCAP) ? L.sidx : P.sidx;
+    for (int k = tid; k < N + nP; k += WG_THREADS) {
+        int idx = 0, p = 0, le = 0;
+        bool caller = false;
+        if (k < N) {
+            const Event e = EVA[k];
+            const int type = e.info & 0xff;
+            if (type == EV_CALLER || type == EV_RESETCAND) { caller = true; idx = e.idx; p = (e.info >> 8) & 0xff; le = e.le; }
+        } else {
+            p = k - N;
+            const int sm = L.gsm[p];
+            if (sm != INT_MAX && sm == L.fcall[p]) { caller = true; idx = sm; le = L.gsmle[p]; }
+        }
+        if (!caller) continue;
+        const bool first = idx == L.fcall[p];
+        int post = 0;
+        if (npost > 0) { // members that stayed matched after their own turn (passive / Msg3 re-entry): rare
+            int prev = -1;
+            for (int j = 0; j < N; j++) {
+                const Event ej = EVA[j];
+                const int tj = ej.info & 0xff;
+                if ((tj == EV_CALLER || tj == EV_RESETCAND) && ((ej.info >> 8) & 0xff) == p && ej.idx < idx && ej.idx > prev)
+                    prev = ej.idx;
+            }
+            const int sm = L.gsm[p];
+            if (!first && sm == L.fcall[p] && sm < idx && sm > prev) prev = sm;
+            for (int j = 0; j < N; j++) {
+                const Event ej = EVA[j];
+                const int tj = ej.info & 0xff;
+                if (((ej.info >> 8) & 0xff) != p || ej.idx >= idx) continue;
+                if (tj == EV_RJOIN && ej.idx > prev) post++;
+                if (tj == EV_PASSIVE && first) post++;
+            }
+        }
+        const int check = 1 + (first ? L.total[p] - le : 0) + post;
+        atomicMax(&L.lcall[p], idx);
+        if (check == 1) {
+            const int s = atomicAdd(&L.scal[S_NS], 1);
+            sing[s] = idx;
+            atomicAdd(&L.scal[S_TXOP], 1);
+        } else if (withnoma) {
+            atomicAdd(&L.scal[S_COLL], check);
+            atomicAdd(&L.scal[S_TXOP], check);
+        } else {
+            atomicAdd(&L.scal[S_COLL], 1);
+            atomicAdd(&L.scal[S_TXOP], 1);
+        }
+    }
+    __syncthreads();
+
+    // RAR grants to the first (nGrantUL-1-grantCheck) singleton callers in index order (Beta.c:336-347)
+    const int ns = L.scal[S_NS];
+    const int G = max(0, P.nGrantUL - 1 - grantCheck);
+    for (int j = tid; j < ns; j += WG_THREADS) {
+        const int my = sing[j];
+        int rank = 0;
+        for (int m = 0; m < ns; m++) rank += sing[m] < my ? 1 : 0;
+        if (rank < G) {
+            int *pkp = reinterpret_cast<int *>(&P.rec[my]) + 3;
+            const int pk = *pkp;
+            const int oldpend = (pk >> PK_PEND_SHIFT) & 7;
+            const int np = oldpend == PEND_RESET ? PEND_GRANTED + 1 : PEND_GRANTED;
+            *pkp = (pk & ~(7 << PK_PEND_SHIFT)) | (np << PK_PEND_SHIFT);
+        }
+    }
+    grantCheck += ns;
+    for (int k = tid; k < NW * nP; k += WG_THREADS) { L.wavehist[k] = 0; L.smidx[k] = INT_MAX; }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// the trial kernel
+// ---------------------------------------------------------------------------------------------
+template <bool GLIBC>
+__global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__restrict__ params) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TrialDev P = params[blockIdx.x];
+    const Lds L = carve(smem, P.nP);
+    const int tid = threadIdx.x;
+    const int nUE = P.nUE, nP = P.nP, aT = P.aT;
+
+    // calloc + initialUE (Beta.c:78-83)
+    for (int i = tid; i < nUE; i += WG_THREADS) {
+        P.rec[i] = make_int4(-1, 0, 0, 0);
+        P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0; P.nd[i] = 0;
+    }
+    for (int k = tid; k < NW * nP; k += WG_THREADS) { L.wavehist[k] = 0; L.smidx[k] = INT_MAX; L.smle[k] = 0; }
+    for (int k = tid; k < nP; k += WG_THREADS) { L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.total[k] = 0; L.gsm[k] = INT_MAX; L.gsmle[k] = 0; }
+    if (tid < 64) L.scal[tid] = 0;
+    if (tid < NW) { L.evcnt[tid] = 0; L.wdraws[tid] = 0; }
+    __syncthreads();
+
+    int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = P.stop;
+    unsigned long long base = 0; // glibc: draws consumed so far (relative to the stream window)
+    unsigned long long steps = 0;
+    int status = PRACH_OK;
+
+    for (int t = 0; t < P.stop; t++) {
+        steps++;
+        tlast = t;
+        if (t % 5 == 0) grantCheck = 0; // Beta.c:112 (hard-coded 5)
+        const int prevAC = activeCheck;
+        if (t % aT == 0 && activeCheck != nUE) activeCheck = P.sched[t / aT]; // Beta.c:121-134
+        if (GLIBC) {
+            const unsigned long long actdraws =
+                P.variant == PRACH_VARIANT_WITHNOMA_C ? 2ull * (unsigned long long)(activeCheck - prevAC) : 0ull;
+            ue_pass<1, true>(P, L, t, prevAC, activeCheck, 0);
+            __syncthreads();
+            unsigned long long tot = actdraws;
+            for (int k = 0; k < NW; k++) tot += L.wdraws[k];
+            if (base + tot > P.stream_len) { status = PRACH_ERR_STREAM; time_exit = t; break; }
+            ue_pass<2, true>(P, L, t, prevAC, activeCheck, base + actdraws);
+            base += tot;
+        } else {
+            ue_pass<0, false>(P, L, t, prevAC, activeCheck, 0);
+        }
+        resolve(P, L, activeCheck, grantCheck);
+        if (L.scal[S_NSUCC] == nUE) { time_exit = t; break; } // Beta.c:180 (loop variable not advanced)
+    }
+    __syncthreads();
+    if (status == PRACH_OK && tlast >= 0) {
+        ue_pass<3, GLIBC>(P, L, tlast + 1, activeCheck, activeCheck, 0);
+    }
+    __syncthreads();
+
+    // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508)
+    const int tend = tlast + 1;
+    long long sumT = 0;
+    int ptcS = 0, fcS = 0;
+    unsigned long long ndS = 0;
+    for (int i = tid; i < nUE; i += WG_THREADS) {
+        const int4 r = P.rec[i];
+        const int act = (r.w >> PK_ACT_SHIFT) & 3, conn = (r.w >> PK_CONN_SHIFT) & 3, pre = (r.w >> PK_PRE_SHIFT) & 0xff,
+                  rar = (r.w >> PK_RAR_SHIFT) & 0xff, mrc = (r.w >> PK_MRC_SHIFT) & 0xff;
+        const int timer = act == ACT_IDLE ? -1 : (act == ACT_DONE ? r.y : tend - r.y);
+        const int ptc = P.ptc[i], fc = P.fcnt[i];
+        if (act == ACT_DONE) { sumT += timer; ptcS += ptc; fcS += fc; }
+        ndS += P.nd[i];
+        P.timers[i] = act == ACT_DONE ? timer : INT_MIN;
+        if (P.logs) {
+            prach_ue_log o;
+            o.idx = i; o.timer = timer; o.active = act - 1; o.txTime = r.x; o.firstTxTime = P.ftt[i];
+            o.secondTxTime = P.stt[i]; o.nowBackoff = now_backoff(r.z, tend); o.preamble = pre - 1;
+            o.preambleChange = pre != 0; o.rarWindow = rar; o.maxRarCounter = mrc; o.preambleTxCounter = ptc;
+            o.msg2Flag = (act == ACT_M3 || act == ACT_DONE); o.connectionRequest = conn == 2 ? 48 : conn;
+            o.msg4Flag = act == ACT_DONE; o.failCount = fc;
+            P.logs[i] = o;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sumT += __shfl_down(sumT, d); ptcS += __shfl_down(ptcS, d); fcS += __shfl_down(fcS, d); ndS += __shfl_down(ndS, d);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&L.scal[S_SUMT_LO]), (unsigned long long)sumT);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&L.scal[S_ND64]), ndS);
+        atomicAdd(&L.scal[S_PTC], ptcS);
+        atomicAdd(&L.scal[S_FC], fcS);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        DevResult o;
+        o.status = status != PRACH_OK ? status : L.scal[S_STATUS];
+        o.time_exit = time_exit;
+        o.nSuccess = L.scal[S_NSUCC];
+        o.collisionPreambles = L.scal[S_COLL];
+        o.totalPreambleTxop = L.scal[S_TXOP];
+        o.activeCheck = activeCheck;
+        o.continueFailed = L.scal[S_CONTF];
+        o.finalSuccess = L.scal[S_FINS];
+        o.ptcSum = L.scal[S_PTC];
+        o.fcSum = L.scal[S_FC];
+        o.draws = GLIBC ? base : *reinterpret_cast<unsigned long long *>(&L.scal[S_ND64]);
+        o.steps = steps;
+        o.sumTimer = *reinterpret_cast<long long *>(&L.scal[S_SUMT_LO]);
+        o.dbg[0] = o.dbg[1] = o.dbg[2] = o.dbg[3] = 0;
+        *P.out = o;
+    }
+}
+
+hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream) {
+    const size_t lds = trial_kernel_lds_bytes(maxP);
+    hipError_t rc;
+    if (rng_mode == PRACH_RNG_GLIBC) {
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&trial_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(trial_kernel<true>, dim3(ntrials), dim3(WG_THREADS), lds, stream, params);
+    } else {
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&trial_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(trial_kernel<false>, dim3(ntrials), dim3(WG_THREADS), lds, stream, params);
+    }
+    return hipGetLastError();
+}
+
+} // namespace prach

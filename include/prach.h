@@ -1,0 +1,137 @@
+/* include/prach.h — C ABI of libprach_hip.so, the MI355X-native replacement for the reference's
+ * per-subframe PRACH random-access simulation loop.
+ *
+ * The reference (yaki-toki/5G-NR-RandomAccess) has no library/FFI seam: each program inlines the
+ * trial body in main() between calloc and free (RandomAccessSimulatorBeta.c:75-210,
+ * RandomAccessWithNOMA.c:226-368, NOMA.c:650-714).  This header is the seam a maintainer would cut
+ * there: ONE call per batch of (seed, nUE) trials replaces
+ *     initialUE            Beta.c:220   WithNOMA:374
+ *     activation loop      Beta.c:121-147 / activateUEs WithNOMA:383
+ *     selectPreamble       Beta.c:229   WithNOMA:475
+ *     preambleCollision    Beta.c:315   WithNOMA:607
+ *     requestResourceAllocation Beta.c:371 WithNOMA:667
+ *     timerIncrease        Beta.c:413   WithNOMA:712
+ *     successUEs           Beta.c:421   WithNOMA:720
+ *     end-of-trial sums    Beta.c:185-197 WithNOMA:337-351
+ * and the writers reproduce saveSimulationLog / saveResult (Beta.c:432-514, WithNOMA:731-825).
+ * Plain C types only; no torch / HIP types cross this boundary.  INTEGRATION.md shows the stub a
+ * maintainer adds on the reference side.
+ */
+#ifndef PRACH_H
+#define PRACH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* which program's loop is reproduced (they differ: SURVEY.md §7.3) */
+#define PRACH_VARIANT_BETA_C      0 /* RandomAccessSimulatorBeta.c */
+#define PRACH_VARIANT_WITHNOMA_C  1 /* RandomAccessWithNOMA.c      */
+#define PRACH_VARIANT_NOMA_C      2 /* NOMA.c (sector power-level grouping) */
+
+#define PRACH_RNG_GLIBC  0 /* the reference's own draw stream: srand(seed)/rand(), bit-exact vs the reference */
+#define PRACH_RNG_PHILOX 1 /* Philox4x32-10, counter = (ue, draw#, nUE, variant), key = seed */
+
+/* status codes (0 = ok).  The reference checks nothing and returns void everywhere; its only
+ * error behaviour is the CLI's message + exit(-1) (WithNOMA:94-204), reproduced by prach_cli. */
+#define PRACH_OK                 0
+#define PRACH_ERR_ARG           -1 /* NULL pointer / non-positive nUE, nPreamble, backoff, accessTime ... */
+#define PRACH_ERR_UNSUPPORTED   -2 /* nPreamble > 254, maxRarWindow > 255, maxMsg2TxCount > 255 */
+#define PRACH_ERR_DEVICE        -3 /* HIP runtime error, no gfx950 device */
+#define PRACH_ERR_STREAM        -4 /* glibc draw stream exhausted (engine retries internally) */
+#define PRACH_ERR_INTERNAL      -5 /* device-side consistency check failed */
+#define PRACH_ERR_IO            -6
+
+typedef struct prach_cfg {
+    int32_t variant;        /* PRACH_VARIANT_* */
+    int32_t uniform;        /* 1: Uniform arrivals over 60 000 ms (Beta.c:92); 0: Beta(3,4) over 10 000 ms (Beta.c:103) */
+    int32_t nUE;            /* Beta.c:75 */
+    int32_t nPreamble;      /* Beta.c:47 */
+    int32_t backoff;        /* backoffIndicator, Beta.c:48 */
+    int32_t nGrantUL;       /* Beta.c:49; effective grants per 5 ms = value-1 (Beta.c:336-338) */
+    int32_t maxRarWindow;   /* Beta.c:52 */
+    int32_t maxMsg2TxCount; /* Beta.c:53 */
+    int32_t accessTime;     /* Beta.c:54 */
+    int32_t rng_mode;       /* PRACH_RNG_* */
+    uint64_t seed;          /* srand(seed), Beta.c:69 */
+    uint64_t stream_offset; /* glibc mode: rand() calls already consumed from this seed's stream
+                               (the reference seeds once per seed and lets the stream run on across
+                               the nUE sweep: Beta.c:66-71) */
+    int32_t max_steps;      /* 0 = run to maxTime; >0 = stop after that many subframes */
+    int32_t reserved;
+    float cellRadius, hBS, hUT; /* parsed by the CLI, never read by the simulation (WithNOMA:80-82) */
+} prach_cfg;
+
+typedef struct prach_result {
+    int32_t status;            /* PRACH_OK or error for this trial */
+    int32_t time_exit;         /* `time` after the loop: printed "Total simulation time" (Beta.c:441) */
+    int32_t maxTime;
+    int32_t nSuccessUE;        /* Beta.c:178 */
+    int32_t failedUEs;         /* Beta.c:185 */
+    int32_t preambleTxCount;   /* Beta.c:194 */
+    int32_t failCounts;        /* WithNOMA:348 */
+    int32_t collisionPreambles, totalPreambleTxop; /* globals Beta.c:41-42 */
+    int32_t activeCheck;       /* Beta.c:200 */
+    int32_t nAccessUE;         /* Beta.c:95 */
+    int32_t continueFaliedUEs, finalSuccessUEs; /* WithNOMA:84-85 */
+    float totalDelay;          /* float running sum in index order, Beta.c:193 */
+    int64_t sumTimer;          /* the same sum in exact integer arithmetic */
+    uint64_t draws;            /* rand() calls consumed (glibc: add to stream_offset for the next trial) */
+    uint64_t steps;            /* subframes executed; UE-subframe updates = nUE * steps */
+} prach_result;
+
+/* the 15 fields saveResult logs per UE (Beta.c:501-508) + failCount (WithNOMA:33) */
+typedef struct prach_ue_log {
+    int32_t idx, timer, active, txTime, firstTxTime, secondTxTime, nowBackoff, preamble, preambleChange,
+        rarWindow, maxRarCounter, preambleTxCounter, msg2Flag, connectionRequest, msg4Flag, failCount;
+} prach_ue_log;
+
+typedef struct prach_timing {
+    double kernel_ms;     /* HIP-event time of the simulation kernel launch(es) of the last call, on the engine's stream */
+    double upload_ms;     /* host->device staging (schedules, parameters, glibc stream seeds) */
+    double total_ms;      /* wall time of the whole call */
+    int32_t launches;     /* kernel launches in the last call */
+    int32_t workgroups;   /* workgroups per launch */
+    uint64_t updates;     /* sum over trials of nUE * steps */
+} prach_timing;
+
+typedef struct prach_engine prach_engine;
+
+/* Engine lifetime: owns the HIP stream and every device buffer (nothing is allocated per subframe,
+ * unlike preambleCollision's malloc per call, Beta.c:319).  device = HIP ordinal. */
+int prach_engine_create(int device, prach_engine **out);
+void prach_engine_destroy(prach_engine *);
+
+/* Run n independent trials concurrently on the device (one workgroup cluster per trial).
+ * ue_logs may be NULL; otherwise ue_logs[k] is NULL or a caller-owned array of cfgs[k].nUE entries. */
+int prach_run_trials(prach_engine *, const prach_cfg *cfgs, int n, prach_result *results,
+                     prach_ue_log *const *ue_logs);
+int prach_last_timing(const prach_engine *, prach_timing *out);
+
+/* engine tunables (names: "cluster" = workgroups cooperating on one trial, 0 = auto) */
+int prach_engine_set(prach_engine *, const char *key, int64_t value);
+
+/* Host-side pieces of the same seam (no device needed) */
+void prach_cfg_defaults(prach_cfg *cfg, int variant); /* Beta.c:47-57 / WithNOMA:70-88 */
+int prach_cfg_validate(const prach_cfg *cfg);
+int prach_max_time(const prach_cfg *cfg);
+/* out[s] = activeCheck after the arrival update of access slot s (Beta.c:121-134); returns #slots */
+int prach_arrival_schedule(const prach_cfg *cfg, int32_t *out, int cap, int32_t *nAccessUE);
+/* k-th .. k+n-th values of srand(seed)/rand() */
+void prach_glibc_stream(uint32_t seed, uint64_t first, uint64_t n, int32_t *out);
+const char *prach_strerror(int status);
+
+/* Text surfaces, byte-compatible with the reference (latency values excepted) */
+size_t prach_format_logs(const prach_ue_log *ue, int nUE, char *buf, size_t cap);           /* Beta.c:501 */
+size_t prach_format_results(const prach_cfg *, const prach_result *, double latency_s, char *buf, size_t cap); /* Beta.c:460-482 / WithNOMA:762-793 */
+size_t prach_format_stdout(const prach_cfg *, const prach_result *, double latency_s, char *buf, size_t cap);  /* Beta.c:200-206,440-446 / WithNOMA:354-361,741-748 */
+int prach_result_file_name(const prach_cfg *, int is_log, char *buf, size_t cap);            /* Beta.c:452-456,490-494 / WithNOMA:754-758,801-805 */
+int prach_write_trial_files(const prach_cfg *, const prach_result *, const prach_ue_log *ue, double latency_s,
+                            const char *root_dir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
