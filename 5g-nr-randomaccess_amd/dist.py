@@ -1,0 +1,80 @@
+"""Trial sharding over the GPUs of one node (one process per GPU, torch.distributed; backend "nccl"
+is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference runs its `--times` seeds x nUE sweep serially (RandomAccessWithNOMA.c:216-221).
+Trials are independent in philox mode, so they are dealt to ranks by descending cost with NO
+data-path collective; after the simulation ONE sum all-reduce merges the per-nUE-point aggregates
+(int64, < 1 KB: latency-bound) and the per-trial rows are gathered to rank 0 for the per-seed files
+and the exact results.csv.  In glibc mode the nUE points of one seed are chained
+through the draw-stream offset, so whole seeds are the sharding unit.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+AGG_FIELDS = ("trials", "nSuccessUE", "preambleTxCount", "sumTimer", "collisionPreambles", "totalPreambleTxop",
+              "continueFaliedUEs", "finalSuccessUEs", "steps", "updates")
+
+
+def trial_cost(cfg) -> int:
+    return int(cfg.nUE) * (60000 if cfg.uniform else 10000)
+
+
+def shard_trials(cfgs, rank: int, world: int, chain_by_seed: bool = False):
+    """Indices of the trials this rank runs. Greedy longest-processing-time dealing (deterministic,
+    identical on every rank).  chain_by_seed keeps all trials of one seed on one rank, in order."""
+    n = len(cfgs)
+    if world <= 1:
+        return list(range(n))
+    if chain_by_seed:
+        seeds = sorted({int(c.seed) for c in cfgs})
+        units = [[i for i in range(n) if int(cfgs[i].seed) == s] for s in seeds]
+    else:
+        units = [[i] for i in range(n)]
+    cost = [sum(trial_cost(cfgs[i]) for i in u) for u in units]
+    order = sorted(range(len(units)), key=lambda k: (-cost[k], k))
+    load = [0] * world
+    mine = []
+    for k in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += cost[k]
+        if r == rank:
+            mine.extend(units[k])
+    return sorted(mine)
+
+
+def aggregate_rows(cfgs, results, points):
+    """int64 [len(points), len(AGG_FIELDS)] sums of this rank's results per nUE point."""
+    agg = np.zeros((len(points), len(AGG_FIELDS)), dtype=np.int64)
+    pos = {p: k for k, p in enumerate(points)}
+    for c, r in zip(cfgs, results):
+        k = pos[int(c.nUE)]
+        row = (1, r.nSuccessUE, r.preambleTxCount, r.sumTimer, r.collisionPreambles, r.totalPreambleTxop,
+               r.continueFaliedUEs, r.finalSuccessUEs, r.steps, int(c.nUE) * int(r.steps))
+        agg[k] += np.array(row, dtype=np.int64)
+    return agg
+
+
+def allreduce_aggregates(agg: np.ndarray, device=None):
+    """ONE sum all-reduce of the aggregate block across ranks (RCCL on GPUs, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return agg
+    t = torch.from_numpy(agg.copy())
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def gather_trial_rows(rows, dst: int = 0):
+    """Per-trial rows (small python tuples) gathered to `dst` in rank order; None elsewhere."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(rows)
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(list(rows), out, dst=dst)
+    if out is None:
+        return None
+    return [r for part in out for r in part]

@@ -1,0 +1,96 @@
+"""N>1 path on CPU: world_size-2 gloo run of the trial sharding + the single aggregate all-reduce +
+the row gather (the same code bench.py / the sweep driver use over RCCL).  The oracle stands in for
+the GPU engine here (tests may do that; the product never does)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    from oracle import binding as ob
+    pkg = g.load_package()
+    import importlib
+    distmod = importlib.import_module("nr_randomaccess_amd.dist")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    points = [600, 900, 1200]
+    cfgs = [pkg.make_cfg(n, variant=1, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(3) for n in points]
+    mine = distmod.shard_trials(cfgs, rank, world)
+    res = []
+    for i in mine:
+        c = cfgs[i]
+        r, _ = ob.run_trial(ob.make_cfg(c.nUE, variant=1), ob.Rng(ob.RNG_PHILOX, int(c.seed)), want_ues=False)
+        res.append(r)
+    agg = distmod.aggregate_rows([cfgs[i] for i in mine], res, points)
+    tot = distmod.allreduce_aggregates(agg)
+    rows = distmod.gather_trial_rows([(i, res[k].nSuccessUE) for k, i in enumerate(mine)], dst=0)
+    if rank == 0:
+        q.put((mine, tot.tolist(), sorted(rows)))
+    else:
+        q.put((mine, None, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_sweep(ob, pkg):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shards = [o[0] for o in outs]
+    assert sorted(shards[0] + shards[1]) == list(range(9)) and not set(shards[0]) & set(shards[1])
+    tot = next(o[1] for o in outs if o[1] is not None)
+    rows = next(o[2] for o in outs if o[2] is not None)
+    # single-process ground truth
+    points = [600, 900, 1200]
+    exp = np.zeros((3, 10), dtype=np.int64)
+    exp_rows = []
+    k = 0
+    for s in range(3):
+        for j, n in enumerate(points):
+            r, _ = ob.run_trial(ob.make_cfg(n, variant=1), ob.Rng(ob.RNG_PHILOX, s), want_ues=False)
+            exp[j] += np.array([1, r.nSuccessUE, r.preambleTxCount, r.sumTimer, r.collisionPreambles, r.totalPreambleTxop,
+                                r.continueFaliedUEs, r.finalSuccessUEs, r.steps, n * r.steps], dtype=np.int64)
+            exp_rows.append((k, r.nSuccessUE))
+            k += 1
+    assert tot == exp.tolist()
+    assert rows == exp_rows
+
+
+def test_shard_trials_properties(pkg):
+    import importlib
+    distmod = importlib.import_module("nr_randomaccess_amd.dist")
+    cfgs = [pkg.make_cfg(n, seed=s) for s in range(7) for n in range(10000, 100001, 10000)]
+    for world in (1, 2, 3, 8):
+        parts = [distmod.shard_trials(cfgs, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(len(cfgs)))
+        loads = [sum(distmod.trial_cost(cfgs[i]) for i in p) for p in parts]
+        assert max(loads) - min(loads) <= 100000 * 10000  # within one largest trial
+        chained = [distmod.shard_trials(cfgs, r, world, chain_by_seed=True) for r in range(world)]
+        assert sorted(sum(chained, [])) == list(range(len(cfgs)))
+        for p in chained:
+            for s in {int(cfgs[i].seed) for i in p}:
+                assert [i for i in p if int(cfgs[i].seed) == s] == [i for i in range(len(cfgs)) if int(cfgs[i].seed) == s]

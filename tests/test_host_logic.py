@@ -1,0 +1,122 @@
+"""Host side of the C ABI (no GPU): defaults, validation, arrival schedule, text surfaces, file
+names, CLI argument behaviour — against the oracle and the reference's golden outputs."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from conftest import load_golden, split_stdout_blocks
+
+
+def test_defaults_match_reference_programs(pkg):
+    b = pkg.make_cfg(100000, variant=pkg.VARIANT_BETA_C)
+    assert (b.nPreamble, b.backoff, b.nGrantUL, b.maxRarWindow, b.maxMsg2TxCount, b.accessTime) == (54, 20, 54, 6, 9, 5)  # Beta.c:47-54
+    w = pkg.make_cfg(100000, variant=pkg.VARIANT_WITHNOMA_C)
+    assert (w.nPreamble, w.backoff, w.nGrantUL, w.maxRarWindow, w.maxMsg2TxCount, w.accessTime) == (54, 20, 12, 6, 9, 5)  # WithNOMA:71-78
+    assert abs(w.cellRadius - 400.0) < 1e-6 and abs(w.hBS - 10.0) < 1e-6 and abs(w.hUT - 1.8) < 1e-6
+
+
+def test_validate(pkg):
+    ok = pkg.make_cfg(1000)
+    assert pkg.lib().prach_cfg_validate(C.byref(ok)) == 0
+    for kw, code in ((dict(nUE=0), -1), (dict(nPreamble=0), -1), (dict(backoff=0), -1), (dict(accessTime=0), -1),
+                     (dict(nGrantUL=0), -1), (dict(rng_mode=7), -1), (dict(variant=9), -1),
+                     (dict(nPreamble=255), -2), (dict(maxRarWindow=256), -2), (dict(maxMsg2TxCount=256), -2)):
+        c = pkg.make_cfg(1000)
+        for k, v in kw.items():
+            setattr(c, k, v)
+        assert pkg.lib().prach_cfg_validate(C.byref(c)) == code, kw
+    assert pkg.lib().prach_cfg_validate(None) == -1
+
+
+@pytest.mark.parametrize("nUE,uniform,aT", [(5000, 1, 5), (10000, 0, 5), (100000, 0, 5), (100000, 1, 5), (30000, 0, 10),
+                                            (777, 0, 7), (1, 0, 5), (64, 1, 6)])
+def test_arrival_schedule_matches_oracle(pkg, ob, nUE, uniform, aT):
+    pc = pkg.make_cfg(nUE, uniform=uniform, accessTime=aT)
+    oc = ob.make_cfg(nUE, uniform=uniform, accessTime=aT)
+    ps, pna = pkg.arrival_schedule(pc)
+    os_, ona = ob.arrival_schedule(oc)
+    assert ps == os_ and pna == ona
+    assert ps[-1] == nUE or uniform  # Beta(3,4) with the 0.0165 normaliser over-delivers: saturates early
+    if not uniform and nUE == 100000 and aT == 5:
+        assert ps.index(100000) * 5 == 7970  # activeCheck saturates at t=7970
+
+
+def _to_presult(pkg, ores):
+    r = pkg.PrachResult()
+    for n, _ in pkg.PrachResult._fields_:
+        if hasattr(ores, n):
+            setattr(r, n, getattr(ores, n))
+    return r
+
+
+@pytest.mark.parametrize("case", ["beta", "noma_uniform", "noma_odd"])
+def test_text_surfaces_byte_identical_to_reference(pkg, ob, case):
+    """prach_format_results / _stdout / _logs on the oracle's numbers reproduce the reference's files."""
+    import hashlib
+    g = load_golden(case)
+    variant = 0 if g["variant"] == "BETA_C" else 1
+    blocks = split_stdout_blocks(g["stdout"])
+    rng = ob.Rng(ob.RNG_GLIBC, 0)
+    for k, tr in enumerate(g["trials"][:2]):
+        ocfg = ob.make_cfg(tr["nUE"], variant=variant, **g["cfg_overrides"])
+        ores, oues = ob.run_trial(ocfg, rng)
+        pcfg = pkg.make_cfg(tr["nUE"], variant=variant, **g["cfg_overrides"])
+        pres = _to_presult(pkg, ores)
+        txt = pkg.format_results(pcfg, pres, 1.5).decode()
+        if variant == 0:
+            assert txt == tr["results_text"] + "1.500000"  # Beta.c:481: latency, no newline
+        else:
+            assert txt == tr["results_text"]
+        so = pkg.format_stdout(pcfg, pres, 1.5).decode()
+        so = "".join(l + "\n" for l in so.split("\n") if l and not l.startswith("Latency:"))
+        assert so == blocks[k]
+        logs = C.cast(oues, C.POINTER(pkg.PrachUeLog))
+        assert hashlib.sha256(pkg.format_logs(logs, tr["nUE"])).hexdigest() == tr["logs_sha256"]
+        name = C.create_string_buffer(256)
+        pkg.lib().prach_result_file_name(C.byref(pcfg), 0, name, 256)
+        assert name.value.decode() == f"{tr['dir']}/{tr['results_file']}"
+        pkg.lib().prach_result_file_name(C.byref(pcfg), 1, name, 256)
+        assert name.value.decode() == f"{tr['dir']}/{tr['logs_file']}"
+
+
+def test_write_trial_files(pkg, ob, tmp_path):
+    ocfg = ob.make_cfg(1200, variant=1)
+    ores, oues = ob.run_trial(ocfg, ob.Rng(ob.RNG_GLIBC, 0))
+    pcfg = pkg.make_cfg(1200, variant=1)
+    rc = pkg.lib().prach_write_trial_files(C.byref(pcfg), C.byref(_to_presult(pkg, ores)),
+                                           C.cast(oues, C.POINTER(pkg.PrachUeLog)), 0.0, str(tmp_path).encode())
+    assert rc == 0
+    d = tmp_path / "NomaBetaResults"
+    assert (d / "0_54_1200_Results.txt").read_bytes() == ob.format_results(ocfg, ores)
+    assert (d / "0_54_UE01200_Logs.txt").read_bytes() == ob.format_logs(oues, 1200)
+
+
+CLI_ERRORS = [  # argv, message (WithNOMA.c:94-157): printed to stdout, exit(-1) == 255
+    (["-t", "0"], "Simulation count must be greater than zero."),
+    (["-d", "3"], "Traffic model just choose 1 or 2"),
+    (["-p", "0"], "Number of preamble must be greater than zero."),
+    (["-b", "0"], "Backoff indicator must be greater than zero."),
+    (["-g", "0"], "The number of Up Link Grant per RAR must be greater than zero."),
+    (["-rc", "0"], "The maximum RAR window size must be greater than zero."),
+    (["-mrc", "0"], "Maximum retransmissions must be greater than zero."),
+    (["-s", "4"], "The size of the subframe must be at least 5."),
+    (["-c", "399"], "The radius of the cell is entered in diameter units and must be greater than 400m."),
+    (["-bs", "9"], "The height of the BS must be between 10m and 20m."),
+    (["-ut", "23"], "The height of the UE must be between 1.5m and 22.5m."),
+]
+
+
+@pytest.mark.parametrize("argv,msg", CLI_ERRORS)
+def test_cli_error_behaviour(pkg, argv, msg):
+    p = subprocess.run([pkg.CLI_PATH] + argv, capture_output=True, text=True)
+    assert p.returncode == 255 and p.stdout == msg
+
+
+def test_cli_usage_on_unknown_flag(pkg):
+    p = subprocess.run([pkg.CLI_PATH, "--bogus", "1"], capture_output=True, text=True)
+    assert p.returncode == 255 and p.stdout.startswith("--times         -t : Simulation times (int)\n")
+    assert "--hut           -u : Height of UE from ground (float)" in p.stdout
+    p = subprocess.run([pkg.CLI_PATH, "-t"], capture_output=True, text=True)  # the reference segfaults here
+    assert p.returncode == 255
