@@ -1,0 +1,183 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libprach_hip.so); the oracle and the golden fixtures are only the checkers.  Bit-exact bar: every
+per-trial counter and every logged field of every UE; totalDelay (float) exact as well."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, split_stdout_blocks
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("time_exit", "nSuccessUE", "failedUEs", "preambleTxCount", "failCounts", "collisionPreambles",
+        "totalPreambleTxop", "activeCheck", "nAccessUE", "continueFaliedUEs", "finalSuccessUEs", "sumTimer", "draws", "steps")
+
+
+def assert_same(pkg, res, logs, ores, oues, what=""):
+    assert res.status == 0, what
+    bad = {k: (getattr(res, k), getattr(ores, k)) for k in KEYS if getattr(res, k) != getattr(ores, k)}
+    assert not bad, (what, bad)
+    assert res.totalDelay == ores.totalDelay, what
+    a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16)
+    b = np.frombuffer(oues, dtype=np.int32).reshape(-1, 16)
+    diff = np.where((a != b).any(axis=1))[0]
+    assert diff.size == 0, (what, diff[:5], a[diff[:3]], b[diff[:3]])
+
+
+ORACLE_CASES = [
+    # variant, nUE, overrides
+    (0, 3000, {}), (1, 3000, {}), (0, 20000, {}), (1, 20000, {}), (1, 30000, {}),
+    (0, 5000, dict(uniform=1, nGrantUL=12)),                       # BASELINE config 1 (Uniform, nUE=5000)
+    (1, 9000, dict(uniform=1, nPreamble=54, backoff=2, nGrantUL=12, maxRarWindow=2)),
+    (0, 1500, dict(nPreamble=2, backoff=3, nGrantUL=3, maxRarWindow=2, maxMsg2TxCount=3, accessTime=6)),
+    (1, 1500, dict(nPreamble=2, backoff=3, nGrantUL=1, maxRarWindow=3, maxMsg2TxCount=0, accessTime=6)),
+    (1, 4000, dict(nPreamble=1, backoff=1, nGrantUL=12, maxRarWindow=2, maxMsg2TxCount=3)),
+    (0, 4000, dict(nPreamble=8, backoff=5, nGrantUL=12, maxRarWindow=2, maxMsg2TxCount=1)),
+    (1, 1500, dict(nPreamble=200, backoff=1, nGrantUL=2, maxRarWindow=2, maxMsg2TxCount=3)),
+    (0, 3000, dict(nPreamble=3, backoff=40, nGrantUL=12, maxRarWindow=6, maxMsg2TxCount=3, accessTime=6)),
+    (1, 9000, dict(nPreamble=64, backoff=10, nGrantUL=8, maxRarWindow=5, maxMsg2TxCount=4, accessTime=10)),
+    (0, 9000, dict(nPreamble=254, backoff=7, nGrantUL=200, maxRarWindow=255, maxMsg2TxCount=255)),
+    (0, 1, {}), (1, 63, {}), (0, 64, {}), (1, 65, {}), (0, 1025, {}),  # ragged sizes around wave / workgroup width
+]
+
+
+@pytest.mark.parametrize("rng_mode", [0, 1])
+@pytest.mark.parametrize("variant,nUE,kw", ORACLE_CASES)
+def test_gpu_equals_oracle(pkg, ob, engine, variant, nUE, kw, rng_mode):
+    seed = 5
+    cfg = pkg.make_cfg(nUE, variant=variant, rng_mode=rng_mode, seed=seed, **kw)
+    (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+    ores, oues = ob.run_trial(ob.make_cfg(nUE, variant=variant, **kw), ob.Rng(rng_mode, seed))
+    assert_same(pkg, res, logs, ores, oues, (variant, nUE, kw, rng_mode))
+
+
+@pytest.mark.parametrize("case", ["beta", "noma_default", "noma_uniform", "noma_odd", "noma_g54", "noma_seed2"])
+def test_gpu_reproduces_reference_files(pkg, engine, case):
+    """glibc mode, nUE sweep chained through the draw-stream offset like the reference's single
+    srand() per seed: Results.txt bytes, stdout block and Logs.txt SHA-256 of EVERY trial of the
+    reference run (up to nUE=100 000) — no oracle involved, only the committed fixtures."""
+    g = load_golden(case)
+    variant = 0 if g["variant"] == "BETA_C" else 1
+    blocks = split_stdout_blocks(g["stdout"])
+    offsets = {}
+    for k, tr in enumerate(g["trials"]):
+        off = offsets.get(tr["seed"], 0)
+        cfg = pkg.make_cfg(tr["nUE"], variant=variant, rng_mode=pkg.RNG_GLIBC, seed=tr["seed"], stream_offset=off,
+                           **g["cfg_overrides"])
+        (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+        assert res.status == 0
+        offsets[tr["seed"]] = off + res.draws
+        txt = pkg.format_results(cfg, res, 0.0).decode()
+        if variant == 0:
+            txt = txt[:-len("0.000000")]
+        assert txt == tr["results_text"], (case, tr["nUE"])
+        so = pkg.format_stdout(cfg, res, 0.0).decode()
+        so = "".join(l + "\n" for l in so.split("\n") if l and not l.startswith("Latency:"))
+        assert so == blocks[k], (case, tr["nUE"])
+        text = pkg.format_logs(logs, tr["nUE"])
+        assert len(text) == tr["logs_bytes"]
+        assert hashlib.sha256(text).hexdigest() == tr["logs_sha256"], (case, tr["nUE"])
+
+
+def test_full_size_100k_vs_oracle_and_properties(pkg, ob, engine):
+    """BASELINE config 2 (nUE=100 000, Beta, 54 preambles, retx 10) at full size."""
+    n = 100000
+    for variant in (0, 1):
+        cfg = pkg.make_cfg(n, variant=variant, rng_mode=pkg.RNG_PHILOX, seed=1)
+        (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+        ores, oues = ob.run_trial(ob.make_cfg(n, variant=variant), ob.Rng(ob.RNG_PHILOX, 1))
+        assert_same(pkg, res, logs, ores, oues, ("100k", variant))
+        a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16)
+        # size-independent properties of the procedure
+        assert res.nSuccessUE + res.failedUEs == n and res.finalSuccessUEs == res.nSuccessUE
+        assert int((a[:, 14] == 1).sum()) == res.nSuccessUE                      # msg4Flag count
+        assert int(a[a[:, 14] == 1, 1].sum()) == res.sumTimer                    # timers of the successful UEs
+        assert (a[a[:, 14] == 1, 2] == 0).all() and (a[a[:, 14] == 1, 12] == 1).all()  # done => active 0, msg2Flag 1
+        assert (a[:, 7] < 54).all() and (a[:, 9] < 6).all() and (a[:, 10] <= 9).all()   # preamble / rarWindow / maxRarCounter ranges
+        assert res.activeCheck == n and res.steps == res.time_exit == 10000 or res.nSuccessUE == n
+        (res2,), (logs2,) = engine.run_trials([cfg], want_logs=True)             # idempotence / determinism
+        assert bytes(logs2) == bytes(logs) and res2.as_dict() == res.as_dict()
+
+
+def test_batch_equals_singles_and_mixed_modes(pkg, ob, engine):
+    """Trials of one call run concurrently (one workgroup each); results are independent of batching,
+    also with mixed RNG modes, variants and sizes in one call."""
+    cfgs = [pkg.make_cfg(n, variant=v, rng_mode=r, seed=s, nGrantUL=gr)
+            for (n, v, r, s, gr) in [(7000, 0, 1, 0, 54), (12000, 1, 1, 1, 12), (3000, 1, 0, 2, 12), (9000, 0, 0, 3, 20),
+                                     (64, 1, 1, 4, 12), (15000, 1, 1, 5, 12), (11000, 0, 1, 6, 54), (2000, 0, 0, 7, 54)]]
+    res_b, logs_b = engine.run_trials(cfgs, want_logs=True)
+    for c, rb, lb in zip(cfgs, res_b, logs_b):
+        (rs,), (ls,) = engine.run_trials([c], want_logs=True)
+        assert rb.as_dict() == rs.as_dict() and bytes(lb) == bytes(ls)
+        ores, oues = ob.run_trial(ob.make_cfg(c.nUE, variant=c.variant, nGrantUL=c.nGrantUL), ob.Rng(c.rng_mode, int(c.seed)))
+        assert_same(pkg, rb, lb, ores, oues, (c.nUE, c.variant, c.rng_mode))
+
+
+def test_many_concurrent_trials_sweep_times(pkg, ob, engine):
+    """BASELINE config 3 shape (nUE sweep x --times), scaled to what the oracle checks in seconds:
+    40 concurrent philox trials, aggregate checked per trial against the oracle."""
+    cfgs = [pkg.make_cfg(n, variant=1, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(10) for n in (2000, 4000, 6000, 8000)]
+    res, _ = engine.run_trials(cfgs)
+    for c, r in zip(cfgs, res):
+        o, _ = ob.run_trial(ob.make_cfg(c.nUE, variant=1), ob.Rng(ob.RNG_PHILOX, int(c.seed)), want_ues=False)
+        assert (r.nSuccessUE, r.time_exit, r.collisionPreambles, r.totalPreambleTxop, r.sumTimer, r.draws) == \
+               (o.nSuccessUE, o.time_exit, o.collisionPreambles, o.totalPreambleTxop, o.sumTimer, o.draws)
+
+
+def test_max_steps_and_stream_offset(pkg, ob, engine):
+    cfg = pkg.make_cfg(8000, variant=1, rng_mode=0, seed=9, max_steps=2500)
+    (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+    ores, oues = ob.run_trial(ob.make_cfg(8000, variant=1, max_steps=2500), ob.Rng(0, 9))
+    assert_same(pkg, res, logs, ores, oues, "max_steps")
+    rng = ob.Rng(0, 9)
+    o1, _ = ob.run_trial(ob.make_cfg(5000, variant=0), rng, want_ues=False)
+    o2, u2 = ob.run_trial(ob.make_cfg(6000, variant=0), rng)
+    cfg2 = pkg.make_cfg(6000, variant=0, rng_mode=0, seed=9, stream_offset=int(o1.draws))
+    (r2,), (l2,) = engine.run_trials([cfg2], want_logs=True)
+    assert_same(pkg, r2, l2, o2, u2, "stream_offset")
+
+
+def test_stream_budget_retry(pkg, ob, engine):
+    """glibc draw-stream window too small on the first attempt: the engine reruns with a larger one."""
+    kw = dict(nPreamble=1, backoff=1, nGrantUL=12, maxRarWindow=2, maxMsg2TxCount=3)
+    engine.set("stream_factor", 20)
+    try:
+        cfg = pkg.make_cfg(4000, variant=1, rng_mode=0, seed=3, **kw)
+        (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+        assert engine.timing().launches >= 2
+    finally:
+        engine.set("stream_factor", 0)
+    ores, oues = ob.run_trial(ob.make_cfg(4000, variant=1, **kw), ob.Rng(0, 3))
+    assert_same(pkg, res, logs, ores, oues, "retry")
+
+
+def test_error_codes(pkg, engine):
+    bad = pkg.make_cfg(1000)
+    bad.nUE = 0
+    with pytest.raises(pkg.PrachError) as ei:
+        engine.run_trials([bad])
+    assert ei.value.status == -1
+    big = pkg.make_cfg(1000, nPreamble=255)
+    with pytest.raises(pkg.PrachError) as ei:
+        engine.run_trials([big])
+    assert ei.value.status == -2
+    assert pkg.lib().prach_run_trials(None, None, 0, None, None) == -1
+
+
+def test_cli_drop_in_files(pkg, engine, tmp_path):
+    """prach_sim with the reference's flags writes the reference's files: first two points of the
+    default RandomAccessWithNOMA run (golden) byte-for-byte, stdout included."""
+    g = load_golden("noma_default")
+    p = subprocess.run([pkg.CLI_PATH, "--sweep", "10000:20000:10000", "--out", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    blocks = split_stdout_blocks(g["stdout"])
+    assert p.stdout.startswith("Traffic model: Beta\n\n")
+    assert split_stdout_blocks(p.stdout) == blocks[:2]
+    for tr in g["trials"][:2]:
+        d = tmp_path / tr["dir"]
+        assert (d / tr["results_file"]).read_text() == tr["results_text"]
+        assert hashlib.sha256((d / tr["logs_file"]).read_bytes()).hexdigest() == tr["logs_sha256"]
