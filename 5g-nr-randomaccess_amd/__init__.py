@@ -14,7 +14,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libprach_hip.so")
+LIB_PATH = os.environ.get("PRACH_LIB") or os.path.join(HERE, "libprach_hip.so")  # PRACH_LIB: diagnostic builds only
 CLI_PATH = os.path.join(HERE, "prach_sim")
 
 VARIANT_BETA_C, VARIANT_WITHNOMA_C, VARIANT_NOMA_C = 0, 1, 2

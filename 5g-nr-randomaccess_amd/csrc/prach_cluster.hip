@@ -1,0 +1,718 @@
+// prach_cluster.hip — the production (Philox) trial kernel: a CLUSTER of G workgroups per trial.
+//
+// Why: one (seed, nUE) trial is 10 000 dependent subframes; a single workgroup (one CU) is bound by
+// its own instruction issue over <=1563 wave-groups per subframe.  Here G workgroups (G CUs) share a
+// trial; G = 1 degenerates to one workgroup per trial for batched sweeps (no exchange at all).
+//
+//  * Ownership is STATIC and INTERLEAVED: 64-UE group g belongs to workgroup g % G, wave
+//    (g / G) % 16.  A UE's record is only ever touched by its owner CU, so UE state needs no
+//    cross-CU coherence (per-XCD L2s are not coherent, MI355X_MICROARCH.md), and the live band of
+//    UEs (arrived, not finished) is spread over all CUs at every moment.  Finished groups are
+//    skipped through an LDS bitmap.
+//  * ONE exchange per subframe: every workgroup publishes a small record (per-preamble histogram of
+//    pre-members, lowest-index would-be caller per preamble, the special events) into its mailbox
+//    with write-through (sc1) stores, arrives at a monotonic device-scope counter, polls it with
+//    relaxed sc1 loads, then every workgroup gathers all mailboxes with sc1 loads and runs the same
+//    resolver redundantly (cdna_hip_programming.md G16: sc1 payload + one agent-scope atomic per
+//    workgroup + sc1 loads; no release/acquire fence, no plain load of shared words).  Mailboxes are
+//    double-buffered by subframe parity; every spin is bounded.
+//  * Interleaving rules out index-ordered prefix sums, so the scan count of the first caller of a
+//    bucket is computed set-wise: total - [caller is a pre-member] - #"early leavers" below it, where
+//    only the early leavers below the workgroup's own lowest caller are published (validated against
+//    the prefix formulation in oracle/phase_model.c).
+//
+// Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351; the
+// decomposition is DESIGN.md §3.
+#include "prach_device.h"
+#include "prach_device_fn.h"
+#include <limits.h>
+
+namespace prach {
+
+namespace {
+
+// Diagnostic build only (make DIAG=1 -> libprach_hip_diag.so): per-phase cycle shares of workgroup 0,
+// written to DevResult.dbg (never to an output the simulation reads).  The shipped library has no stamps.
+#ifdef PRACH_STAMPS
+#define STAMP(k)                                                                                       \
+    do {                                                                                               \
+        if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); stamps[k] += now_ - tprev; tprev = now_; } \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+constexpr int EVC_CALLER = 1, EVC_RESETCAND = 2, EVC_RJOIN = 3, EVC_LEAVER = 4;
+constexpr int EVCAPC = 4096; // gathered events per subframe held in LDS
+constexpr int SCAPC = 2048;  // singleton callers per subframe held in LDS
+constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups)
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+enum { C_NSUCC = 0, C_COLL, C_TXOP, C_CONTF, C_NS, C_NRC, C_NRJ, C_STATUS, C_NEV, C_NCAND, C_OVF, C_NSUCCTOT, C_NTOT,
+       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20 };
+
+struct CLds {
+    int2 *gev;    // [EVCAPC] gathered events of all workgroups
+    int *sidx;    // [SCAPC]
+    int *rclist;  // [RCCAP]
+    int *scal;    // [64]
+    unsigned *dead; // [DEADW]
+    int *evoff;   // [MAXG+1]
+    int *bins;    // [GBINS] grant selection: singleton callers per index bin (then exclusive prefix)
+    int *wtot;    // [NW]
+    int *hist, *mloc, *total, *fcall, *lcall, *nlv, *fie; // [nP] each
+};
+constexpr int GBINS = 1024;
+constexpr int MAXG = 64; // the gather's header phase is one wavefront: lane = workgroup
+
+__device__ __forceinline__ CLds ccarve(char *smem, int nP) {
+    CLds L;
+    L.gev = reinterpret_cast<int2 *>(smem);
+    int *ip = reinterpret_cast<int *>(smem + sizeof(int2) * EVCAPC);
+    L.sidx = ip; ip += SCAPC;
+    L.rclist = ip; ip += RCCAP;
+    L.scal = ip; ip += 64;
+    L.dead = reinterpret_cast<unsigned *>(ip); ip += DEADW;
+    L.evoff = ip; ip += MAXG + 16;
+    L.bins = ip; ip += GBINS;
+    L.wtot = ip; ip += NW;
+    L.hist = ip; ip += nP; L.mloc = ip; ip += nP; L.total = ip; ip += nP; L.fcall = ip; ip += nP;
+    L.lcall = ip; ip += nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
+    return L;
+}
+
+// shared words: every access is a device-scope relaxed atomic == global_load/store ... sc1
+__device__ __forceinline__ int ld_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld_sc1_64(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1_64(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct FastMods { FastMod nP, backoff, aT, five; };
+
+struct Ctx {
+    int b, G, evw, mbstride;
+    int *mbox;      // [2][G][mbstride]
+    unsigned *bar;  // monotonic arrival counter of this trial
+    int2 *cand;     // this workgroup's private early-leaver candidate scratch
+};
+
+__device__ __forceinline__ int *mb_of(const Ctx &C, int parity, int wg) { return C.mbox + ((size_t)parity * C.G + wg) * C.mbstride; }
+
+// ---------------------------------------------------------------------------------------------
+// pass over the groups this workgroup owns.  FINAL: only the deferred apply of the last subframe.
+// ---------------------------------------------------------------------------------------------
+template <bool FINAL>
+__device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, const Ctx &C, const FastMods &FM, const int t, const int prevAC,
+                                             const int activeCheck, int *mbev) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nP = P.nP, aT = P.aT, nUE = P.nUE;
+    const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
+    const int ngroups = (activeCheck + 63) >> 6;
+    const int tp = t - 1;
+    int c_succ = 0, c_contf = 0;
+    const int tmod = t % aT;
+    const FastMod fmP = FM.nP, fmB = FM.backoff, fmA = FM.aT, fm5 = FM.five;
+
+    // software pipeline: the next live group's record (and Philox draw index) is in flight while the
+    // current group is processed (state is L2-resident; the pass is latency-, not bandwidth-bound)
+    auto next_live = [&](int jj) -> int {
+        for (;; jj += NW) {
+            if (C.b + C.G * jj >= ngroups) return -1;
+            if (!((L.dead[(jj >> 5) & (DEADW - 1)] >> (jj & 31)) & 1u)) return jj;
+        }
+    };
+    int jn = next_live(w);
+    int4 rn = make_int4(-1, 0, 0, 0);
+    unsigned ndn = 0;
+    if (jn >= 0) {
+        const int in = (C.b + C.G * jn) * 64 + lane;
+        if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (!FINAL) ndn = P.nd[in]; }
+    }
+    while (jn >= 0) {
+        const int j = jn;
+        const int g = C.b + C.G * j;
+        const int i = g * 64 + lane;
+        const bool valid = i < activeCheck;
+        const int4 r = rn;
+        unsigned ndc = ndn;
+        jn = next_live(j + NW);
+        rn = make_int4(-1, 0, 0, 0);
+        ndn = 0;
+        if (jn >= 0) {
+            const int in = (C.b + C.G * jn) * 64 + lane;
+            if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (!FINAL) ndn = P.nd[in]; }
+        }
+        bool nd_dirty = false;
+        UeState u = unpack(r);
+        bool dirty = false;
+
+        // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
+        if (u.pend != PEND_NONE) {
+            if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
+                u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
+                if (u.pend == PEND_RESET) u.bo = 0;
+            } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
+                u.tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
+            } else if (u.pend == PEND_RESET) {
+                const int q = u.bo, tmp = u.tx;
+                const int bumped = L.fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
+                const int x = slot_align_fm(tp + bumped + tmp, fmA);
+                if (x == tp) { u.bo = 0; u.tx = tp + 1; }
+                else { u.tx = x; u.bo = x; }
+            } else if (u.pend == PEND_PASSIVE) {
+                if (L.fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
+            } else { // PEND_RJOIN
+                if (L.lcall[u.pre - 1] > i) u.tx = tp + 1;
+            }
+            u.pend = PEND_NONE;
+            dirty = true;
+        }
+        if (FINAL) {
+            if (dirty) P.rec[i] = pack(u);
+            continue;
+        }
+        // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
+        if (valid && i >= prevAC) {
+            u.act = ACT_M1; u.tx = t + 1; u.tb = t;
+            P.ftt[i] = t + 1;
+            if (withnoma) { ndc = 2; nd_dirty = true; }
+            dirty = true;
+        }
+
+        const bool isM1 = u.act == ACT_M1;
+        const int nb = now_backoff(u.bo, t);
+        const bool firstsel = isM1 && u.pre == 0;
+        const bool contend = isM1 && u.pre != 0 && nb <= 0;
+        const bool expire = contend && (u.rar + 1 >= P.maxRarWindow);
+        const bool reset = expire && u.mrc >= P.maxMsg2;
+        const bool retx = expire && !reset;
+        const bool m3due = u.act == ACT_M3 && u.tx == t;
+        const bool m3first = m3due && u.conn == 0, m3to = m3due && u.conn != 0;
+        const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
+        const bool busy = isM1 || m3due;
+
+        if (!__any(busy || dirty)) {
+            // nothing happens in this group; retire it for good once every UE in it has finished
+            if (__all(i >= nUE || u.act == ACT_DONE) && lane == 0) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
+            continue;
+        }
+
+        int d1 = 0, d2 = 0;
+        if (__any(need > 0)) {
+            const unsigned k = ndc;
+            d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, (unsigned)P.variant);
+            if (__any(need > 1))
+                d2 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, (unsigned)P.variant);
+            if (need > 0) { ndc = k + (unsigned)need; nd_dirty = true; }
+        }
+
+        // ---- selectPreamble / requestResourceAllocation on own state ----
+        const int oldp = u.pre - 1;
+        const bool member_pre = isM1 && u.tx == t && u.pre != 0; // matched by a preambleCollision scan right now
+        int evtype = 0, evp = 0, evq = 0;
+        bool eclass = false; // pre-member that leaves its bucket at its own turn without calling on it
+        if (firstsel) { // Beta.c:231-239
+            u.pre = fastmod(d1, fmP) + 1; u.rar = 0; u.mrc = 0; u.bo = 0;
+            P.ptc[i] = 1;
+            if (withnoma) P.fcnt[i] = 0;
+            if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = u.pre - 1; }
+            dirty = true;
+        } else if (isM1 && u.pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
+            if (member_pre) { u.pend = withnoma ? PEND_STAY : PEND_PASSIVE; dirty = true; } // WithNOMA:310 calls anyway
+        } else if (contend) {
+            u.rar++; // Beta.c:245
+            dirty = true;
+            if (reset) { // Beta.c:250-281
+                if (withnoma) { c_contf++; P.fcnt[i] = P.fcnt[i] + 1; }
+                const int newp = fastmod(d1, fmP);
+                const int tmp = fastmod(d2, fmB);
+                u.rar = 0; u.mrc = 0; u.tb = t;
+                P.ptc[i] = 1; P.ftt[i] = t + 1;
+                u.pre = newp + 1;
+                if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
+                    u.pend = PEND_RESET; u.tx = tmp; u.bo = oldp;
+                    eclass = true;
+                    if (tmp == 0 && aT > 1 && tmod == 1) { evtype = EVC_RESETCAND; evp = newp; evq = oldp; }
+                } else {
+                    u.tx = slot_align_fm(u.tx + tmp, fmA);
+                    u.bo = enc_backoff(u.tx - t, t);
+                    if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = newp; }
+                }
+            } else if (retx) { // Beta.c:282-308
+                u.rar = 0; u.mrc++;
+                P.ptc[i] = P.ptc[i] + 1;
+                const int tmp = fastmod(d1, fmB);
+                u.tx = slot_align_fm(t + tmp, fmA);
+                u.bo = enc_backoff(u.tx - t, t);
+                P.stt[i] = u.tx;
+                if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = oldp; } // the "late joiner"
+                else if (member_pre) eclass = true;
+            } else if (member_pre) {
+                u.pend = PEND_STAY;
+            }
+        } else if (m3first) { // Beta.c:372-383
+            u.conn = 1;
+            const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
+            if ((double)pf > 0.1) { u.act = ACT_DONE; u.tb = (t - u.tb) + 6; c_succ++; }
+            else { u.conn = 2; u.tx += 48; }
+            dirty = true;
+        } else if (m3to) { // Msg3 timeout, Beta.c:384-410
+            c_contf++;
+            const int tmp = fastmod(d1, fmB);
+            u.tx = slot_align_fm(u.tx + tmp, fm5); // hard-coded accessTime = 5, Beta.c:389
+            u.act = ACT_M1;
+            u.bo = enc_backoff(u.tx - t, t);
+            u.pre = fastmod(d2, fmP) + 1;
+            u.tb = t; u.rar = 0; u.mrc = 0; u.conn = 0;
+            if (withnoma) P.fcnt[i] = P.fcnt[i] + 1;
+            if (u.tx == t) { u.pend = PEND_RJOIN; evtype = EVC_RJOIN; evp = u.pre - 1; }
+            dirty = true;
+        }
+
+        // ---- bucket bookkeeping (workgroup-level LDS atomics) ----
+        if (member_pre) atomicAdd(&L.hist[oldp], 1);
+        if (u.pend == PEND_STAY) { if (__atomic_load_n(&L.mloc[oldp], __ATOMIC_RELAXED) > i) atomicMin(&L.mloc[oldp], i); }
+        if (evtype == EVC_CALLER) atomicMin(&L.mloc[evp], i);
+        {
+            const unsigned long long em = __ballot(evtype != 0);
+            if (em) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.scal[C_NEV], __popcll(em));
+                base = __shfl(base, 0);
+                if (evtype != 0) {
+                    const int slot = base + __popcll(em & lanemask_lt(lane));
+                    const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
+                    if (slot < C.evw) st_sc1_64(reinterpret_cast<long long *>(mbev) + slot,
+                                                (long long)(unsigned)i | ((long long)(evtype | (ispre << 3) | (evp << 8) | (evq << 16)) << 32));
+                }
+            }
+            const unsigned long long cm = __ballot(eclass);
+            if (cm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.scal[C_NCAND], __popcll(cm));
+                base = __shfl(base, 0);
+                if (eclass) C.cand[base + __popcll(cm & lanemask_lt(lane))] = make_int2(i, oldp);
+            }
+        }
+        if (nd_dirty) P.nd[i] = ndc;
+        if (dirty) P.rec[i] = pack(u);
+    }
+    if (!FINAL) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        if (lane == 0) {
+            if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
+            if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
+        }
+    }
+}
+
+// Reset-cycle candidates (Beta.c:250-281 with tmp == 0 on a subframe = 1 mod accessTime): candidate i
+// re-joins (and calls on its NEW preamble) iff nobody called on its OLD preamble before it, and a
+// re-join is itself a call that later candidates must see.  Inherently sequential in index order,
+// but tiny: ONE wavefront keeps the per-bucket first-caller table in registers (lane = bucket, up to
+// 4 x 64 buckets) and walks the index-sorted candidates with v_readlane — no LDS round trip per step.
+__device__ __forceinline__ int fc_get(int f0, int f1, int f2, int f3, int q) {
+    const int l = q & 63;
+    switch (q >> 6) {
+    case 0: return __builtin_amdgcn_readlane(f0, l);
+    case 1: return __builtin_amdgcn_readlane(f1, l);
+    case 2: return __builtin_amdgcn_readlane(f2, l);
+    default: return __builtin_amdgcn_readlane(f3, l);
+    }
+}
+__device__ __forceinline__ void resolve_reset_candidates(const CLds &L, const int nrc_in, const int nP) {
+    const int lane = threadIdx.x & 63;
+    const int n = __builtin_amdgcn_readfirstlane(nrc_in);
+    int f0 = lane < nP ? L.fcall[lane] : INT_MAX, f1 = lane + 64 < nP ? L.fcall[lane + 64] : INT_MAX,
+        f2 = lane + 128 < nP ? L.fcall[lane + 128] : INT_MAX, f3 = lane + 192 < nP ? L.fcall[lane + 192] : INT_MAX;
+    // rank-sort the candidate list by UE index into L.sidx (free at this point of the subframe)
+    for (int c = lane; c < n; c += 64) {
+        const int myidx = L.gev[L.rclist[c]].x;
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += L.gev[L.rclist[j]].x < myidx ? 1 : 0;
+        L.sidx[rank] = L.rclist[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int base = 0; base < n; base += 64) {
+        const int m = min(64, n - base);
+        int slot = 0, cidx = 0, cinfo = 0;
+        if (lane < m) { slot = L.sidx[base + lane]; const int2 e = L.gev[slot]; cidx = e.x; cinfo = e.y; }
+        int cancelled = 0;
+        for (int s_ = 0; s_ < m; s_++) {
+            const int idx = __builtin_amdgcn_readlane(cidx, s_), info = __builtin_amdgcn_readlane(cinfo, s_);
+            const int p = (info >> 8) & 0xff, q = (info >> 16) & 0xff;
+            if (fc_get(f0, f1, f2, f3, q) < idx) { // bumped before its turn: does not re-join
+                if (lane == s_) cancelled = 1;
+            } else if (idx < fc_get(f0, f1, f2, f3, p)) { // its call becomes the first one on p
+                if (lane == (p & 63)) {
+                    switch (p >> 6) { case 0: f0 = idx; break; case 1: f1 = idx; break; case 2: f2 = idx; break; default: f3 = idx; break; }
+                }
+            }
+        }
+        if (lane < m && cancelled) L.gev[slot].y = 0;
+    }
+    if (lane < nP) L.fcall[lane] = f0;
+    if (lane + 64 < nP) L.fcall[lane + 64] = f1;
+    if (lane + 128 < nP) L.fcall[lane + 128] = f2;
+    if (lane + 192 < nP) L.fcall[lane + 192] = f3;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = blockIdx.x % nT, b = blockIdx.x / nT;
+    const TrialDev P = params[T];
+    const CLds L = ccarve(smem, P.nP);
+    const int tid = threadIdx.x;
+    const int nUE = P.nUE, nP = P.nP, aT = P.aT;
+    const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
+
+    FastMods FM;
+    FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
+    Ctx C;
+    C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox; C.bar = P.bar;
+    const int totgroups = (nUE + 63) >> 6;
+    const int lgroups = (totgroups + G - 1) / G; // local groups of any workgroup (upper bound)
+    C.cand = P.cand + (size_t)b * lgroups * 64;
+
+    // calloc + initialUE (Beta.c:78-83) for the groups this workgroup owns
+    for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
+        const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
+        if (g < totgroups && i < nUE) {
+            P.rec[i] = make_int4(-1, 0, 0, 0);
+            P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0; P.nd[i] = 0;
+        }
+    }
+    for (int k = tid; k < nP; k += WG_THREADS) {
+        L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0;
+    }
+    if (tid < 64) L.scal[tid] = 0;
+    for (int k = tid; k < DEADW; k += WG_THREADS) L.dead[k] = 0;
+    __syncthreads();
+
+    int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = P.stop;
+    unsigned long long steps = 0;
+    int status = (lgroups > DEADW * 32) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+#ifdef PRACH_STAMPS
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    unsigned long long statN = 0, maxN = 0, statRC = 0, statNS = 0, maxNS = 0;
+#endif
+
+    for (int t = 0; t < P.stop && status == PRACH_OK; t++) {
+        steps++;
+        tlast = t;
+        if (t % 5 == 0) grantCheck = 0; // Beta.c:112 (hard-coded 5)
+        const int prevAC = activeCheck;
+        if (t % aT == 0 && activeCheck != nUE) activeCheck = P.sched[t / aT]; // Beta.c:121-134
+        const int parity = t & 1;
+        int *const mymb = mb_of(C, parity, b);
+        int *const mbev = mymb + 4 + 2 * nP;
+
+        cluster_pass<false>(P, L, C, FM, t, prevAC, activeCheck, mbev);
+        __syncthreads();
+        STAMP(0);
+
+        // early leavers below this workgroup's lowest caller are the only ones a rank can need
+        const int ncand = L.scal[C_NCAND];
+        for (int k = tid; k < ncand; k += WG_THREADS) {
+            const int2 c = C.cand[k];
+            if (c.x < L.mloc[c.y]) {
+                const int slot = atomicAdd(&L.scal[C_NEV], 1);
+                if (slot < C.evw) st_sc1_64(reinterpret_cast<long long *>(mbev) + slot, (long long)(unsigned)c.x | ((long long)(EVC_LEAVER | (c.y << 8)) << 32));
+            }
+        }
+        __syncthreads();
+        // publish: histogram, lowest caller per bucket, header; then — after every storing wave has drained its
+        // write-through stores and the workgroup has met — ONE lane stores the tag (t+1) the consumers poll.
+        unsigned long long hdr;
+        {
+            const int nevraw = L.scal[C_NEV];
+            for (int k = tid; k < nP; k += WG_THREADS) { st_sc1(mymb + 4 + k, L.hist[k]); st_sc1(mymb + 4 + nP + k, L.mloc[k]); }
+            hdr = (unsigned long long)(unsigned)(t + 1) | ((unsigned long long)(unsigned)min(nevraw, C.evw) << 16) |
+                  ((unsigned long long)(nevraw > C.evw ? 1u : 0u) << 39) | ((unsigned long long)(unsigned)L.scal[C_NSUCC] << 40);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ONE 8-byte write-through store publishes {tag = t+1, #events, overflow, #successes so far}
+        if (tid == 0) st_sc1_64(reinterpret_cast<long long *>(mymb), (long long)hdr);
+        STAMP(1);
+        // per-subframe LDS state for the gather (the apply of the NEXT pass reads fcall / lcall)
+        for (int k = tid; k < nP; k += WG_THREADS) { L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0; }
+        if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
+        // header phase: lane l of the first wavefront waits for workgroup l's tag (relaxed sc1 polls, bounded),
+        // then reads its counts; exclusive prefix of the event counts by wave shuffles.
+        if (tid < 64) {
+            int nev = 0, nsuc = 0, ovf = 0, bad = 0;
+            if (tid < G) {
+                const long long *mb = reinterpret_cast<const long long *>(mb_of(C, parity, tid));
+                unsigned spins = 0;
+                unsigned long long h = (unsigned long long)ld_sc1_64(mb);
+                while ((int)(h & 0xffffu) != ((t + 1) & 0xffff)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > SPIN_LIMIT) { bad = 1; break; }
+                    h = (unsigned long long)ld_sc1_64(mb);
+                }
+                nev = (int)((h >> 16) & 0x1fffu); ovf = (int)((h >> 39) & 1u); nsuc = (int)(h >> 40);
+            }
+            int x = nev;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (tid >= d) x += y; }
+            L.evoff[tid] = x - nev;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { nsuc += __shfl_down(nsuc, d); ovf |= __shfl_down(ovf, d); bad |= __shfl_down(bad, d); }
+            if (tid == 63) L.scal[C_NTOT] = x;
+            if (tid == 0) { L.scal[C_NSUCCTOT] = nsuc; L.scal[C_OVF] = ovf; if (bad) L.scal[C_STATUS] = PRACH_ERR_INTERNAL; }
+        }
+        __syncthreads();
+        STAMP(2);
+        if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
+        const int N = L.scal[C_NTOT];
+        if (L.scal[C_OVF] || N > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
+
+        // payload phase: ONE round of sc1 loads — histograms / lowest callers of every workgroup, and every event
+        { // hist / mloc of every workgroup: 8-byte sc1 loads, all issued before the first LDS atomic
+            const int pairs = nP; // (4 + 2nP) ints per mailbox start 8-byte aligned: hist/mloc = nP pairs
+            for (int k0 = tid; k0 < G * pairs; k0 += 2 * WG_THREADS) {
+                const int k1 = k0 + WG_THREADS;
+                const int wg0 = k0 / pairs, q0 = k0 - wg0 * pairs;
+                const long long v0 = ld_sc1_64(reinterpret_cast<const long long *>(mb_of(C, parity, wg0) + 4) + q0);
+                long long v1 = 0;
+                int wg1 = 0, q1 = 0;
+                if (k1 < G * pairs) { wg1 = k1 / pairs; q1 = k1 - wg1 * pairs; v1 = ld_sc1_64(reinterpret_cast<const long long *>(mb_of(C, parity, wg1) + 4) + q1); }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (h == 1 && k1 >= G * pairs) break;
+                    const long long v = h ? v1 : v0;
+                    const int q = h ? q1 : q0;
+#pragma unroll
+                    for (int z = 0; z < 2; z++) {
+                        const int kk = 2 * q + z, val = z ? (int)(v >> 32) : (int)(unsigned)v;
+                        if (kk < nP) { if (val) atomicAdd(&L.total[kk], val); }
+                        else if (val != INT_MAX) atomicMin(&L.fcall[kk - nP], val);
+                    }
+                }
+            }
+        }
+        for (int k = tid; k < N; k += WG_THREADS) {
+            int lo = 0, hi = G; // workgroup whose segment holds event k
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.evoff[mid] <= k) lo = mid; else hi = mid; }
+            const long long e = ld_sc1_64(reinterpret_cast<const long long *>(mb_of(C, parity, lo) + 4 + 2 * nP) + (k - L.evoff[lo]));
+            L.gev[k] = make_int2((int)(unsigned)e, (int)(e >> 32));
+        }
+        __syncthreads();
+        // classify the gathered events (fcall now holds the lowest DEFINITE caller of every bucket)
+        for (int k = tid; k < N; k += WG_THREADS) {
+            const int2 ev = L.gev[k];
+            const int type = ev.y & 7;
+            if (type == EVC_RESETCAND) {
+                // a call on its old bucket by a definite caller with a lower index bumps it: cannot re-join
+                // (99.7 % of them; only the survivors need the index-ordered treatment)
+                if (L.fcall[(ev.y >> 16) & 0xff] < ev.x) L.gev[k].y = 0;
+                else { const int s = atomicAdd(&L.scal[C_NRC], 1); if (s < RCCAP) L.rclist[s] = k; }
+            } else if (type == EVC_RJOIN) atomicAdd(&L.scal[C_NRJ], 1);
+        }
+        __syncthreads();
+        STAMP(3);
+
+        // ---- resolve (identical on every workgroup of the cluster) ----
+        const int nrc = L.scal[C_NRC];
+        if (nrc > 0) { // reset cycles that could land on this subframe: decided strictly in index order
+            if (nrc > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (tid < 64) resolve_reset_candidates(L, nrc, nP);
+            __syncthreads();
+        }
+        STAMP(4);
+        for (int k = tid; k < N; k += WG_THREADS) {
+            const int2 e = L.gev[k];
+            const int type = e.y & 7, p = (e.y >> 8) & 0xff;
+            if (type == EVC_LEAVER) { if (e.x < L.fcall[p]) atomicAdd(&L.nlv[p], 1); }
+            else if ((type == EVC_CALLER || type == EVC_RESETCAND) && e.x == L.fcall[p]) L.fie[p] = 1;
+        }
+        __syncthreads();
+        STAMP(5);
+#ifdef PRACH_STAMPS
+        if (tid == 0) { statN += (unsigned long long)N; if ((unsigned long long)N > maxN) maxN = N; statRC += (unsigned long long)nrc; }
+#endif
+        const int nrj = L.scal[C_NRJ];
+        int my_coll = 0, my_txop = 0;
+        for (int k = tid; k < N + nP; k += WG_THREADS) {
+            int idx = 0, p = 0, ispre = 0;
+            bool caller = false;
+            if (k < N) {
+                const int2 e = L.gev[k];
+                const int type = e.y & 7;
+                if (type == EVC_CALLER || type == EVC_RESETCAND) { caller = true; idx = e.x; p = (e.y >> 8) & 0xff; ispre = (e.y >> 3) & 1; }
+            } else {
+                p = k - N;
+                if (L.fcall[p] != INT_MAX && !L.fie[p]) { caller = true; idx = L.fcall[p]; ispre = 1; } // a STAY pre-member calls first
+            }
+            if (!caller) continue;
+            const bool first = idx == L.fcall[p];
+            int rj = 0;
+            if (nrj > 0) { // Msg3-timeout re-entries that stayed matched since the previous call on this bucket (rare)
+                int prev = (!first) ? L.fcall[p] : -1;
+                for (int j = 0; j < N; j++) {
+                    const int2 ej = L.gev[j];
+                    const int tj = ej.y & 7;
+                    if ((tj == EVC_CALLER || tj == EVC_RESETCAND) && ((ej.y >> 8) & 0xff) == p && ej.x < idx && ej.x > prev) prev = ej.x;
+                }
+                for (int j = 0; j < N; j++) {
+                    const int2 ej = L.gev[j];
+                    if ((ej.y & 7) == EVC_RJOIN && ((ej.y >> 8) & 0xff) == p && ej.x < idx && ej.x > prev) rj++;
+                }
+            }
+            const int check = 1 + (first ? L.total[p] - ispre - L.nlv[p] : 0) + rj;
+            if (L.lcall[p] < idx) atomicMax(&L.lcall[p], idx);
+            if (check == 1) {
+                const int s = atomicAdd(&L.scal[C_NS], 1);
+                if (s < SCAPC) L.sidx[s] = idx;
+                my_txop += 1;
+            } else if (withnoma) { // WithNOMA:650-652
+                my_coll += check; my_txop += check;
+            } else { // Beta.c:349-351
+                my_coll += 1; my_txop += 1;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { my_coll += __shfl_down(my_coll, d); my_txop += __shfl_down(my_txop, d); }
+        if ((tid & 63) == 0) { if (my_coll) atomicAdd(&L.scal[C_COLL], my_coll); if (my_txop) atomicAdd(&L.scal[C_TXOP], my_txop); }
+        __syncthreads();
+        STAMP(6);
+        const int ns = L.scal[C_NS];
+        if (ns > SCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+        const int Gr = max(0, P.nGrantUL - 1 - grantCheck); // Beta.c:336-347
+        if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
+            // the Gr lowest-index singleton callers, in O(ns): counts per index bin (1024 bins over [0,nUE)),
+            // block-wide exclusive prefix, whole bins below the crossing bin are granted, the crossing bin is
+            // ranked exactly.  The grant itself is ONE atomicOr into the UE's record by the UE's owner.
+            const int binshift = P.binshift;
+            L.bins[tid] = 0;
+            __syncthreads();
+            for (int j = tid; j < ns; j += WG_THREADS) atomicAdd(&L.bins[L.sidx[j] >> binshift], 1);
+            __syncthreads();
+            {
+                const int c = L.bins[tid];
+                int x = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((tid & 63) >= d) x += y; }
+                if ((tid & 63) == 63) L.wtot[tid >> 6] = x;
+                __syncthreads();
+                int add = 0;
+                for (int k = 0; k < (tid >> 6); k++) add += L.wtot[k];
+                L.bins[tid] = x - c + add; // exclusive prefix
+            }
+            __syncthreads();
+            // whole bins below the crossing bin: granted; members of the (single) crossing bin: compacted, then
+            // ranked among themselves
+            if (tid == 0) L.scal[C_NCROSS] = 0;
+            __syncthreads();
+            for (int j = tid; j < ns; j += WG_THREADS) {
+                const int my = L.sidx[j];
+                const int bin = my >> binshift;
+                const int before = L.bins[bin];
+                if (before >= Gr) continue;
+                const int cnt = (bin + 1 < GBINS ? L.bins[bin + 1] : ns) - before;
+                if (before + cnt <= Gr) { if (((my >> 6) % G) == b) atomicOr(reinterpret_cast<unsigned *>(&P.rec[my]) + 3, PK_GRANT_BIT); }
+                else { const int s_ = atomicAdd(&L.scal[C_NCROSS], 1); if (s_ < RCCAP) L.rclist[s_] = my; }
+            }
+            __syncthreads();
+            const int ncross = L.scal[C_NCROSS];
+            if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (tid < ncross) {
+                const int my = L.rclist[tid];
+                int rank = L.bins[my >> binshift];
+                for (int m = 0; m < ncross; m++) rank += L.rclist[m] < my ? 1 : 0;
+                if (rank < Gr && ((my >> 6) % G) == b) atomicOr(reinterpret_cast<unsigned *>(&P.rec[my]) + 3, PK_GRANT_BIT);
+            }
+        }
+        grantCheck += ns;
+        const int nsucc_tot = L.scal[C_NSUCCTOT];
+        __syncthreads();
+        STAMP(7);
+#ifdef PRACH_STAMPS
+        if (tid == 0) { statNS += (unsigned long long)ns; if ((unsigned long long)ns > maxNS) maxNS = ns; }
+#endif
+        if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
+        if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
+    }
+    __syncthreads();
+    if (status == PRACH_OK && tlast >= 0) cluster_pass<true>(P, L, C, FM, tlast + 1, activeCheck, activeCheck, nullptr);
+    __syncthreads();
+
+    // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of the owned UEs
+    const int tend = tlast + 1;
+    long long sumT = 0;
+    int ptcS = 0, fcS = 0;
+    unsigned long long ndS = 0;
+    for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
+        const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
+        if (g >= totgroups || i >= nUE) continue;
+        const UeState u = unpack(P.rec[i]);
+        const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
+        const int ptc = P.ptc[i], fc = P.fcnt[i];
+        if (u.act == ACT_DONE) { sumT += timer; ptcS += ptc; fcS += fc; }
+        ndS += P.nd[i];
+        P.timers[i] = u.act == ACT_DONE ? timer : INT_MIN;
+        if (P.logs) {
+            prach_ue_log o;
+            o.idx = i; o.timer = timer; o.active = u.act - 1; o.txTime = u.tx; o.firstTxTime = P.ftt[i];
+            o.secondTxTime = P.stt[i]; o.nowBackoff = now_backoff(u.bo, tend); o.preamble = u.pre - 1;
+            o.preambleChange = u.pre != 0; o.rarWindow = u.rar; o.maxRarCounter = u.mrc; o.preambleTxCounter = ptc;
+            o.msg2Flag = (u.act == ACT_M3 || u.act == ACT_DONE); o.connectionRequest = u.conn == 2 ? 48 : u.conn;
+            o.msg4Flag = u.act == ACT_DONE; o.failCount = fc;
+            P.logs[i] = o;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        sumT += __shfl_down(sumT, d); ptcS += __shfl_down(ptcS, d); fcS += __shfl_down(fcS, d); ndS += __shfl_down(ndS, d);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&L.scal[C_SUMT]), (unsigned long long)sumT);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&L.scal[C_ND]), ndS);
+        atomicAdd(&L.scal[C_PTC], ptcS);
+        atomicAdd(&L.scal[C_FC], fcS);
+    }
+    __syncthreads();
+    if (tid == 0) { // DevResult was zeroed by the engine before the launch
+        DevResult *o = P.out;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&o->sumTimer), *reinterpret_cast<unsigned long long *>(&L.scal[C_SUMT]));
+        atomicAdd(&o->draws, *reinterpret_cast<unsigned long long *>(&L.scal[C_ND]));
+        atomicAdd(&o->ptcSum, L.scal[C_PTC]);
+        atomicAdd(&o->fcSum, L.scal[C_FC]);
+        atomicAdd(&o->nSuccess, L.scal[C_NSUCC]);
+        atomicAdd(&o->finalSuccess, L.scal[C_NSUCC]);
+        atomicAdd(&o->continueFailed, L.scal[C_CONTF]);
+        if (status != PRACH_OK) atomicMin(&o->status, status);
+        if (b == 0) {
+#ifdef PRACH_STAMPS
+            for (int k = 0; k < 8; k++) o->stamps6[k] = stamps[k];
+            o->dbg[0] = statN; o->dbg[1] = maxN; o->dbg[2] = statRC; o->dbg[3] = (statNS << 20) | maxNS;
+#endif
+            o->time_exit = time_exit;
+            o->collisionPreambles = L.scal[C_COLL];
+            o->totalPreambleTxop = L.scal[C_TXOP];
+            o->activeCheck = activeCheck;
+            o->steps = steps;
+        }
+    }
+}
+
+size_t cluster_kernel_lds_bytes(int nP) {
+    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 7 * nP);
+}
+
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream) {
+    const size_t lds = cluster_kernel_lds_bytes(maxP);
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL(cluster_kernel, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
+    return hipGetLastError();
+}
+
+} // namespace prach

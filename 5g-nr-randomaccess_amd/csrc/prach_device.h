@@ -24,8 +24,10 @@ constexpr int ACT_M1 = 2;   // active ==  1 (Msg1/Msg2 phase)
 constexpr int ACT_M3 = 3;   // active ==  2 (Msg3/Msg4 phase)
 
 // what the deferred "apply" of the previous subframe still owes this UE
-constexpr int PEND_NONE = 0, PEND_STAY = 1, PEND_CALLER = 2, PEND_RESET = 3, PEND_PASSIVE = 4, PEND_RJOIN = 5,
-              PEND_GRANTED = 6;
+constexpr int PEND_NONE = 0, PEND_STAY = 1, PEND_CALLER = 2, PEND_RESET = 3, PEND_PASSIVE = 4, PEND_RJOIN = 5;
+// bit 31 of the packed word: the resolver granted this (singleton-calling) UE an UL grant — set with ONE
+// fire-and-forget atomicOr by the UE's owner workgroup, consumed by the next pass's apply
+constexpr unsigned PK_GRANT_BIT = 0x80000000u;
 // ordered "special" events handed to the resolver
 constexpr int EV_CALLER = 1, EV_RESETCAND = 2, EV_PASSIVE = 3, EV_RJOIN = 4;
 
@@ -42,6 +44,7 @@ struct DevResult {
     unsigned long long draws, steps;
     long long sumTimer;
     unsigned long long dbg[4];
+    unsigned long long stamps6[8]; // diagnostic build: cycles per phase (pass, publish, barrier, gather, resolve, grants)
 };
 
 struct TrialDev {
@@ -58,6 +61,12 @@ struct TrialDev {
     prach_ue_log *logs;          // nullable
     int *timers;                 // per UE: final timer if succeeded, else INT_MIN
     DevResult *out;
+    // cluster kernel (prach_cluster.hip) only
+    int evw, mbstride;           // events per mailbox, mailbox stride (ints)
+    int binshift;                // grant selection: UE index >> binshift < 1024
+    int *mbox;                   // [2][G][mbstride] write-through mailboxes
+    unsigned *bar;               // arrival counter (zeroed before every launch)
+    int2 *cand;                  // early-leaver candidate scratch, nUE + 64*G entries
 };
 
 constexpr int WG_THREADS = 1024;
@@ -68,5 +77,8 @@ constexpr int RCCAP = 256;          // reset-cycle re-join candidates per subfra
 
 size_t trial_kernel_lds_bytes(int nP);
 hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream);
+size_t cluster_kernel_lds_bytes(int nP);
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
+constexpr int CLUSTER_MAX_G = 64;
 
 } // namespace prach

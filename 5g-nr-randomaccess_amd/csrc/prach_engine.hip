@@ -5,8 +5,10 @@
 // entry point that simulates returns PRACH_ERR_DEVICE.
 #include "prach_device.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits.h>
 #include <vector>
@@ -31,6 +33,9 @@ struct prach_engine {
     size_t arena_cap = 0;
     prach_timing last{};
     int64_t opt_stream_factor = 0; // glibc: initial draws-per-UE budget override (0 = auto)
+    int64_t opt_cluster = 0;       // workgroups per trial for the Philox cluster kernel (0 = auto)
+    int64_t opt_legacy = 0;        // 1: run Philox trials on the one-workgroup trial_kernel as well
+    int last_G = 0;
 };
 
 namespace {
@@ -38,11 +43,12 @@ namespace {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct TrialLayout {
-    size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, end;
+    size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, bar, cand, end;
     size_t stream_len, sched_len;
+    int evw, mbstride;
 };
 
-TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t stream_len) {
+TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t stream_len, int G) {
     TrialLayout L{};
     size_t o = base;
     const size_t n = (size_t)c.nUE;
@@ -58,6 +64,14 @@ TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t
     L.logs = want_logs ? take(sizeof(prach_ue_log) * n) : 0;
     L.timers = take(4 * n);
     L.out = take(sizeof(DevResult));
+    L.evw = 0; L.mbstride = 0; L.mbox = L.bar = L.cand = 0;
+    if (G > 0) { // cluster kernel: mailboxes, arrival counter, early-leaver candidate scratch
+        L.evw = G == 1 ? 4096 : 512;
+        L.mbstride = (int)align_up((size_t)(4 + 2 * c.nPreamble + 2 * L.evw), 4);
+        L.mbox = take(4 * (size_t)2 * G * L.mbstride);
+        L.bar = take(256);
+        L.cand = take(8 * (n + 64 * (size_t)G + 64));
+    }
     L.end = o;
     return L;
 }
@@ -100,17 +114,19 @@ int prach_engine_create(int device, prach_engine **out) {
 
 void prach_engine_destroy(prach_engine *e) {
     if (!e) return;
-    hipSetDevice(e->device);
-    if (e->arena) hipFree(e->arena);
-    if (e->ev0) hipEventDestroy(e->ev0);
-    if (e->ev1) hipEventDestroy(e->ev1);
-    if (e->stream) hipStreamDestroy(e->stream);
+    (void)hipSetDevice(e->device);
+    if (e->arena) (void)hipFree(e->arena);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
 int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (!e || !key) return PRACH_ERR_ARG;
     if (std::strcmp(key, "stream_factor") == 0) { e->opt_stream_factor = value; return PRACH_OK; }
+    if (std::strcmp(key, "cluster") == 0) { if (value < 0 || value > CLUSTER_MAX_G) return PRACH_ERR_ARG; e->opt_cluster = value; return PRACH_OK; }
+    if (std::strcmp(key, "legacy") == 0) { e->opt_legacy = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }
 
@@ -122,7 +138,7 @@ int prach_last_timing(const prach_engine *e, prach_timing *out) {
 
 // one launch over the trials idx[0..m) (all the same rng_mode); attempt = glibc stream retry level
 static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, prach_result *results,
-                     prach_ue_log *const *ue_logs, int attempt, double &kernel_ms, double &upload_ms) {
+                     prach_ue_log *const *ue_logs, int attempt, int G, double &kernel_ms, double &upload_ms) {
     const int rng_mode = cfgs[idx[0]].rng_mode;
     std::vector<TrialLayout> lay(m);
     size_t o = align_up(sizeof(TrialDev) * (size_t)m, 256);
@@ -131,7 +147,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         const prach_cfg &c = cfgs[idx[k]];
         const bool wl = ue_logs && ue_logs[idx[k]];
         const size_t sl = rng_mode == PRACH_RNG_GLIBC ? (size_t)stream_budget(c, attempt, e->opt_stream_factor) : 0;
-        lay[k] = layout_trial(c, o, wl, sl);
+        lay[k] = layout_trial(c, o, wl, sl, G);
         o = lay[k].end;
         if (c.nPreamble > maxP) maxP = c.nPreamble;
     }
@@ -170,6 +186,17 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.logs = L.logs ? reinterpret_cast<prach_ue_log *>(A + L.logs) : nullptr;
         d.timers = reinterpret_cast<int *>(A + L.timers);
         d.out = reinterpret_cast<DevResult *>(A + L.out);
+        d.evw = L.evw; d.mbstride = L.mbstride;
+        d.binshift = 0;
+        while (((c.nUE - 1) >> d.binshift) >= 1024) d.binshift++;
+        d.mbox = G > 0 ? reinterpret_cast<int *>(A + L.mbox) : nullptr;
+        d.bar = G > 0 ? reinterpret_cast<unsigned *>(A + L.bar) : nullptr;
+        d.cand = G > 0 ? reinterpret_cast<int2 *>(A + L.cand) : nullptr;
+        if (G > 0) { // words polled / accumulated in-kernel are zeroed before EVERY launch
+            HIPCHK(hipMemsetAsync(A + L.out, 0, sizeof(DevResult), e->stream));
+            HIPCHK(hipMemsetAsync(A + L.bar, 0, 256, e->stream));
+            HIPCHK(hipMemsetAsync(A + L.mbox, 0, 4 * (size_t)2 * G * L.mbstride, e->stream)); // tags: 0 never equals t+1
+        }
         sched.assign(L.sched_len, c.nUE);
         prach_arrival_schedule(&c, sched.data(), (int)L.sched_len, &nAccess[k]);
         HIPCHK(hipMemcpyAsync(A + L.sched, sched.data(), 4 * L.sched_len, hipMemcpyHostToDevice, e->stream));
@@ -187,14 +214,16 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     upload_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
 
     HIPCHK(hipEventRecord(e->ev0, e->stream));
-    HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
+    if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
+    else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     kernel_ms += ms;
     e->last.launches++;
-    e->last.workgroups = m;
+    e->last.workgroups = m * (G > 0 ? G : 1);
+    e->last_G = G;
 
     std::vector<int32_t> timers;
     for (int k = 0; k < m; k++) {
@@ -220,6 +249,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         r.sumTimer = dr.sumTimer;
         r.draws = dr.draws;
         r.steps = dr.steps;
+        if (std::getenv("PRACH_PRINT_STAMPS"))
+            std::fprintf(stderr, "[prach stamps/step] pass=%.0f publish=%.0f barrier=%.0f gather=%.0f r1b=%.0f leavers=%.0f checks=%.0f grants=%.0f cycles | N avg %.1f max %llu, resetcand avg %.2f, singles avg %.1f max %llu\n",
+                         dr.stamps6[0] / (double)dr.steps, dr.stamps6[1] / (double)dr.steps, dr.stamps6[2] / (double)dr.steps, dr.stamps6[3] / (double)dr.steps,
+                         dr.stamps6[4] / (double)dr.steps, dr.stamps6[5] / (double)dr.steps, dr.stamps6[6] / (double)dr.steps, dr.stamps6[7] / (double)dr.steps,
+                         dr.dbg[0] / (double)dr.steps, dr.dbg[1], dr.dbg[2] / (double)dr.steps, (dr.dbg[3] >> 20) / (double)dr.steps, dr.dbg[3] & 0xfffff);
         if (dr.status != PRACH_OK) continue;
         // totalDelay is a FLOAT running sum in index order (Beta.c:186,193): exact in integer
         // arithmetic while it stays below 2^24, otherwise replay the float additions on the host.
@@ -254,9 +288,28 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
         std::vector<int> idx;
         for (int k = 0; k < n; k++)
             if (cfgs[k].rng_mode == mode) idx.push_back(k);
+        if (idx.empty()) continue;
+        bool cluster_ok = mode == PRACH_RNG_PHILOX && !e->opt_legacy;
+        for (int k : idx) cluster_ok = cluster_ok && cfgs[k].nUE <= (1 << 20); // dead-group bitmap / header granule limits
+        if (cluster_ok) {
+            // production path: cluster kernel, G workgroups per trial (all clusters must be co-resident:
+            // at most one 1024-thread workgroup per CU is assumed, 256 CUs)
+            int minGroups = INT_MAX;
+            for (int k : idx) minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
+            int G = (int)e->opt_cluster;
+            if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= 128 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
+            while (G > 1 && (size_t)G * idx.size() > 192) G /= 2; // every cluster must be co-resident (256 CUs)
+            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, G, kernel_ms, upload_ms);
+            if (rc != PRACH_OK) return rc;
+            std::vector<int> again; // a per-subframe capacity of the cluster kernel was exceeded: exact rerun on trial_kernel
+            for (int k : idx)
+                if (results[k].status == PRACH_ERR_INTERNAL) again.push_back(k);
+            idx.swap(again);
+            if (idx.empty()) continue;
+        }
         int attempt = 0;
         while (!idx.empty()) {
-            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, attempt, kernel_ms, upload_ms);
+            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, attempt, 0, kernel_ms, upload_ms);
             if (rc != PRACH_OK) return rc;
             std::vector<int> again; // glibc trials whose draw-stream window ran out: rerun with a larger one
             for (int k : idx)

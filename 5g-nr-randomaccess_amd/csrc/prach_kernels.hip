@@ -22,37 +22,10 @@
 // RNG: Philox4x32-10 per (UE, draw#) lane-locally, or the reference's own glibc rand() stream
 // addressed through an index-ordered prefix sum of per-UE draw counts (bit-exact vs the reference).
 #include "prach_device.h"
+#include "prach_device_fn.h"
 #include <limits.h>
 
 namespace prach {
-
-// ---------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int slot_align(int sub, int aT) { // Beta.c:268-277
-    const int m = sub % aT;
-    return m == 0 ? sub + 1 : (m == 1 ? sub : sub + (aT - m + 1));
-}
-__device__ __forceinline__ int now_backoff(int bo, int t) { return bo > 0 ? max(bo - t, 0) : bo; }
-__device__ __forceinline__ int enc_backoff(int X, int t) { return X > 0 ? t + X : X; }
-
-__device__ __forceinline__ int philox_draw31(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2,
-                                             unsigned c3) {
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return (int)(c0 >> 1);
-}
-
-__device__ __forceinline__ unsigned long long lanemask_le(int lane) {
-    return lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
-}
-__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 // LDS carve-up (dynamic shared memory, 16-byte aligned base; prach_device.h sizes)
 struct Lds {
@@ -128,7 +101,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
         const int i = g * 64 + lane;
         const bool valid = i < activeCheck;
         int4 r = make_int4(-1, 0, 0, 0);
-        if (valid) r = P.rec[i];
+        if (valid) r = load_rec(&P.rec[i]);
         int tx = r.x, tb = r.y, bo = r.z;
         int act = (r.w >> PK_ACT_SHIFT) & 3, conn = (r.w >> PK_CONN_SHIFT) & 3, pre = (r.w >> PK_PRE_SHIFT) & 0xff,
             rar = (r.w >> PK_RAR_SHIFT) & 0xff, mrc = (r.w >> PK_MRC_SHIFT) & 0xff, pend = (r.w >> PK_PEND_SHIFT) & 7;
@@ -137,9 +110,9 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
         if (MODE != 2) {
             // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
             if (pend != PEND_NONE) {
-                if (pend >= PEND_GRANTED) { // singleton caller that got an UL grant (Beta.c:338-343)
+                if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
                     act = ACT_M3; tx = tp + 11; conn = 0;
-                    if (pend > PEND_GRANTED) bo = 0;
+                    if (pend == PEND_RESET) bo = 0;
                 } else if (pend == PEND_STAY || pend == PEND_CALLER) {
                     tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
                 } else if (pend == PEND_RESET) {
@@ -478,11 +451,7 @@ __device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const i
         int rank = 0;
         for (int m = 0; m < ns; m++) rank += sing[m] < my ? 1 : 0;
         if (rank < G) {
-            int *pkp = reinterpret_cast<int *>(&P.rec[my]) + 3;
-            const int pk = *pkp;
-            const int oldpend = (pk >> PK_PEND_SHIFT) & 7;
-            const int np = oldpend == PEND_RESET ? PEND_GRANTED + 1 : PEND_GRANTED;
-            *pkp = (pk & ~(7 << PK_PEND_SHIFT)) | (np << PK_PEND_SHIFT);
+            atomicOr(reinterpret_cast<unsigned *>(&P.rec[my]) + 3, PK_GRANT_BIT);
         }
     }
     grantCheck += ns;

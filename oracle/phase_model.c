@@ -32,7 +32,7 @@ typedef struct {
     uint32_t nd;
 } mue_t;
 
-typedef struct { int idx, type, p, q, le; } ev_t;
+typedef struct { int idx, type, p, q, le, is_pre; } ev_t;
 
 typedef struct {
     const oracle_cfg *cfg;
@@ -81,6 +81,8 @@ int model_run_trial(const oracle_cfg *cfg, int rng_mode, uint64_t seed, const in
     if (nranges < 1) nranges = 1;
     mue_t *U = (mue_t *)calloc((size_t)nUE, sizeof(mue_t));
     ev_t *EV = (ev_t *)malloc(sizeof(ev_t) * (size_t)nUE);
+    int *Eidx = (int *)malloc(sizeof(int) * (size_t)nUE), *Ep = (int *)malloc(sizeof(int) * (size_t)nUE), nE = 0; /* 'early leaver' pre-members (cluster-kernel rank formulation) */
+    int formula_mismatch = 0;
     int *evcnt = (int *)calloc((size_t)nranges, sizeof(int));
     int *evstart = (int *)calloc((size_t)nranges + 1, sizeof(int));
     int *rhist = (int *)calloc((size_t)nranges * nP, sizeof(int));
@@ -115,6 +117,7 @@ int model_run_trial(const oracle_cfg *cfg, int rng_mode, uint64_t seed, const in
         /* ranges of [0, activeCheck): contiguous, multiples of 64 like the kernel's wave ranges */
         int groups = (activeCheck + 63) / 64, gper = (groups + nranges - 1) / nranges;
         memset(rhist, 0, sizeof(int) * (size_t)nranges * nP);
+        nE = 0;
         for (int k = 0; k < nranges * nP; k++) { rsm_idx[k] = INT_MAX; rsm_le[k] = 0; }
 
         /* ---- pass 1 (glibc only): apply(t-1) + activation + per-range draw counts ---- */
@@ -223,6 +226,9 @@ int model_run_trial(const oracle_cfg *cfg, int rng_mode, uint64_t seed, const in
                         }
                     }
                     if (R.rng_mode == ORACLE_RNG_GLIBC && (int)(off - off0) != dc_pred) R.overflow = 2; /* draw-count prediction must hold */
+                    /* E class: a pre-member that leaves its bucket at its own turn without calling on it
+                     * (retransmit rescheduled elsewhere, or any reset cycle) */
+                    if (member_pre && ((u->pend == PEND_NONE && u->txTime != t) || u->pend == PEND_RESET)) { Eidx[nE] = i; Ep[nE] = oldp; nE++; }
                     if (member_pre) run[oldp]++;
                     /* STAYMIN candidate: first PEND_STAY of its bucket in this range */
                     if (u->pend == PEND_STAY && rsm_idx[(size_t)rr * nP + oldp] == INT_MAX) {
@@ -231,7 +237,7 @@ int model_run_trial(const oracle_cfg *cfg, int rng_mode, uint64_t seed, const in
                     }
                     if (evtype) {
                         ev_t *e = &EV[evstart[rr] + evcnt[rr]++];
-                        e->idx = i; e->type = evtype; e->p = evp; e->q = evq;
+                        e->idx = i; e->type = evtype; e->p = evp; e->q = evq; e->is_pre = member_pre && oldp == evp;
                         e->le = run[evp]; /* local #pre-members of bucket evp with idx <= i (this range) */
                     }
                 }
@@ -277,9 +283,9 @@ int model_run_trial(const oracle_cfg *cfg, int rng_mode, uint64_t seed, const in
         if (nev + nP > scap) { scap = (nev + nP) * 2 + 64; single_idx = (int *)realloc(single_idx, sizeof(int) * (size_t)scap); }
         int ns = 0;
         for (int k = 0; k < nev + nP; k++) {
-            int idx, p, le;
-            if (k < nev) { if (L[k].type != EV_CALLER && L[k].type != EV_RESETCAND) continue; idx = L[k].idx; p = L[k].p; le = L[k].le; }
-            else { p = k - nev; if (sm_idx[p] == INT_MAX || sm_idx[p] != fcall[p]) continue; idx = sm_idx[p]; le = sm_le[p]; }
+            int idx, p, le, is_pre;
+            if (k < nev) { if (L[k].type != EV_CALLER && L[k].type != EV_RESETCAND) continue; idx = L[k].idx; p = L[k].p; le = L[k].le; is_pre = L[k].is_pre; }
+            else { p = k - nev; if (sm_idx[p] == INT_MAX || sm_idx[p] != fcall[p]) continue; idx = sm_idx[p]; le = sm_le[p]; is_pre = 1; }
             int first = idx == fcall[p];
             int prev = -1; /* previous caller on the same bucket */
             int post = 0;
@@ -294,6 +300,13 @@ int model_run_trial(const oracle_cfg *cfg, int rng_mode, uint64_t seed, const in
                 if (L[j].type == EV_PASSIVE && first) post++; /* idx < fcall: still a member at the first call */
             }
             int check = 1 + (first ? total[p] - le : 0) + post;
+            { /* the cluster kernel's set-based formulation of the same count: no index-ordered prefix needed */
+                int nlv = 0, rj = 0;
+                for (int j = 0; j < nE; j++) nlv += Ep[j] == p && Eidx[j] < idx;
+                for (int j = 0; j < nev; j++) rj += L[j].type == EV_RJOIN && L[j].p == p && L[j].idx < idx && L[j].idx > prev;
+                int check2 = 1 + (first ? total[p] - is_pre - nlv : 0) + rj;
+                if (check2 != check) formula_mismatch = 1;
+            }
             calls++;
             if (idx > lcall[p]) lcall[p] = idx;
             if (check == 1) { totalPreambleTxop++; single_idx[ns++] = idx; }
@@ -363,8 +376,8 @@ int model_run_trial(const oracle_cfg *cfg, int rng_mode, uint64_t seed, const in
     res->sumTimer = sumTimer; res->steps = steps; res->collisionCalls = calls;
     res->draws = rng_mode == ORACLE_RNG_GLIBC ? R.base - stream_off : 0;
     if (rng_mode == ORACLE_RNG_PHILOX) { uint64_t d = 0; for (int i = 0; i < nUE; i++) d += U[i].nd; res->draws = d; }
-    int rc = R.overflow ? -2 - R.overflow : 0; /* -3 stream exhausted, -4 draw-count misprediction */
-    free(U); free(EV); free(evcnt); free(evstart); free(rhist); free(rsm_idx); free(rsm_le); free(rdraws);
+    int rc = R.overflow ? -2 - R.overflow : (formula_mismatch ? -5 : 0); /* -3 stream exhausted, -4 draw-count misprediction */
+    free(Eidx); free(Ep); free(U); free(EV); free(evcnt); free(evstart); free(rhist); free(rsm_idx); free(rsm_le); free(rdraws);
     free(total); free(fcall); free(lcall); free(sm_idx); free(sm_le); free(granted); free(sched);
     return rc;
 }
