@@ -160,7 +160,7 @@ def main():
                        "rng": "philox4x32-10 (production mode)", "trials_per_step_per_gpu": 1,
                        "updates_per_step_per_gpu": per_launch_updates, "parallelism": f"trials sharded over {world} GPU(s), one RCCL sum all-reduce of the aggregates"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "prach::trial_kernel<false>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "prach::cluster_kernel (G=32 workgroups per trial)", "kernel_ms": k_ms,
                          "note": "single-trial workload: 1e4 dependent subframes over <=1.6 MB of L2-resident state; bounded by per-subframe latency, not HBM (DESIGN.md §5)"},
             "success_ratio_mean": agg_succ / (args.steps * world * args.nue),
         }
