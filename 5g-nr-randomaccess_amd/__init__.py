@@ -98,6 +98,9 @@ def lib():
         L.prach_format_stdout.restype = C.c_size_t
         L.prach_result_file_name.argtypes = [C.POINTER(PrachCfg), C.c_int, C.c_char_p, C.c_size_t]
         L.prach_write_trial_files.argtypes = [C.POINTER(PrachCfg), C.POINTER(PrachResult), C.POINTER(PrachUeLog), C.c_double, C.c_char_p]
+        L.prach_noma_activation_table.argtypes = [C.POINTER(PrachCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.prach_format_noma_line.argtypes = [C.POINTER(PrachCfg), C.POINTER(PrachResult), C.c_char_p, C.c_size_t]
+        L.prach_format_noma_line.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -105,7 +108,7 @@ def lib():
 EXPORTS = ("prach_engine_create", "prach_engine_destroy", "prach_engine_set", "prach_run_trials", "prach_last_timing",
            "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_arrival_schedule", "prach_glibc_stream",
            "prach_strerror", "prach_format_logs", "prach_format_results", "prach_format_stdout",
-           "prach_result_file_name", "prach_write_trial_files")
+           "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line")
 
 
 def make_cfg(nUE, variant=VARIANT_BETA_C, uniform=0, rng_mode=RNG_GLIBC, seed=0, stream_offset=0, **kw) -> PrachCfg:
@@ -198,4 +201,23 @@ def format_results(cfg, res, latency=0.0) -> bytes:
 def format_stdout(cfg, res, latency=0.0) -> bytes:
     buf = C.create_string_buffer(4096)
     n = lib().prach_format_stdout(C.byref(cfg), C.byref(res), latency, buf, 4096)
+    return buf.raw[:n]
+
+
+def noma_activation_table(cfg: PrachCfg):
+    """(preamble0, sector, gain, ln gain, draws) per UE of the NOMA.c variant (host side, no GPU)."""
+    import numpy as np
+    n = cfg.nUE
+    pre0, sec = np.empty(n, np.int32), np.empty(n, np.int32)
+    gain, lgain = np.empty(n, np.float64), np.empty(n, np.float64)
+    nd = np.empty(n, np.uint32)
+    rc = lib().prach_noma_activation_table(C.byref(cfg), pre0.ctypes.data, sec.ctypes.data, gain.ctypes.data, lgain.ctypes.data, nd.ctypes.data)
+    if rc != OK:
+        raise PrachError(rc, "(prach_noma_activation_table)")
+    return pre0, sec, gain, lgain, nd
+
+
+def format_noma_line(cfg, res) -> bytes:
+    buf = C.create_string_buffer(256)
+    n = lib().prach_format_noma_line(C.byref(cfg), C.byref(res), buf, 256)
     return buf.raw[:n]

@@ -67,6 +67,10 @@ struct TrialDev {
     int *mbox;                   // [2][G][mbstride] write-through mailboxes
     unsigned *bar;               // arrival counter (zeroed before every launch)
     int2 *cand;                  // early-leaver candidate scratch, nUE + 64*G entries
+    // NOMA.c variant (prach_noma.hip) only: the host-built activation table
+    const int *n_pre0, *n_sector;
+    const double *n_gain, *n_lgain;
+    const unsigned *n_nd0;
 };
 
 constexpr int WG_THREADS = 1024;
@@ -80,5 +84,7 @@ hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode
 size_t cluster_kernel_lds_bytes(int nP);
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
 constexpr int CLUSTER_MAX_G = 64;
+size_t noma_kernel_lds_bytes(int nP);
+hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int maxP, hipStream_t stream);
 
 } // namespace prach

@@ -44,6 +44,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, bar, cand, end;
+    size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0;
     size_t stream_len, sched_len;
     int evw, mbstride;
 };
@@ -71,6 +72,10 @@ TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t
         L.mbox = take(4 * (size_t)2 * G * L.mbstride);
         L.bar = take(256);
         L.cand = take(8 * (n + 64 * (size_t)G + 64));
+    }
+    L.n_pre0 = L.n_sector = L.n_gain = L.n_lgain = L.n_nd0 = 0;
+    if (c.variant == PRACH_VARIANT_NOMA_C) {
+        L.n_pre0 = take(4 * n); L.n_sector = take(4 * n); L.n_gain = take(8 * n); L.n_lgain = take(8 * n); L.n_nd0 = take(4 * n);
     }
     L.end = o;
     return L;
@@ -201,6 +206,23 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         prach_arrival_schedule(&c, sched.data(), (int)L.sched_len, &nAccess[k]);
         HIPCHK(hipMemcpyAsync(A + L.sched, sched.data(), 4 * L.sched_len, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream)); // staging vector is reused
+        d.n_pre0 = d.n_sector = nullptr; d.n_gain = d.n_lgain = nullptr; d.n_nd0 = nullptr;
+        if (c.variant == PRACH_VARIANT_NOMA_C) { // activeUE's per-UE attributes (double-precision libm work): host, once per trial
+            const size_t nn = (size_t)c.nUE;
+            std::vector<int32_t> pre0(nn), sec(nn);
+            std::vector<double> gn(nn), lg(nn);
+            std::vector<uint32_t> nd0(nn);
+            int trc = prach_noma_activation_table(&c, pre0.data(), sec.data(), gn.data(), lg.data(), nd0.data());
+            if (trc != PRACH_OK) return trc;
+            HIPCHK(hipMemcpy(A + L.n_pre0, pre0.data(), 4 * nn, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(A + L.n_sector, sec.data(), 4 * nn, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(A + L.n_gain, gn.data(), 8 * nn, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(A + L.n_lgain, lg.data(), 8 * nn, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(A + L.n_nd0, nd0.data(), 4 * nn, hipMemcpyHostToDevice));
+            d.n_pre0 = reinterpret_cast<const int *>(A + L.n_pre0); d.n_sector = reinterpret_cast<const int *>(A + L.n_sector);
+            d.n_gain = reinterpret_cast<const double *>(A + L.n_gain); d.n_lgain = reinterpret_cast<const double *>(A + L.n_lgain);
+            d.n_nd0 = reinterpret_cast<const unsigned *>(A + L.n_nd0);
+        }
         if (rng_mode == PRACH_RNG_GLIBC) {
             strm.resize(L.stream_len);
             prach_glibc_stream((uint32_t)c.seed, c.stream_offset, L.stream_len, strm.data());
@@ -214,7 +236,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     upload_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
 
     HIPCHK(hipEventRecord(e->ev0, e->stream));
-    if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
+    if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, maxP, e->stream));
+    else if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -278,16 +301,26 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
     for (int k = 0; k < n; k++) {
         int v = prach_cfg_validate(&cfgs[k]);
         if (v != PRACH_OK) return v;
-        if (cfgs[k].variant == PRACH_VARIANT_NOMA_C) return PRACH_ERR_UNSUPPORTED;
+        if (cfgs[k].variant == PRACH_VARIANT_NOMA_C && (cfgs[k].rng_mode != PRACH_RNG_PHILOX || cfgs[k].nPreamble > 64 || cfgs[k].uniform))
+            return PRACH_ERR_UNSUPPORTED; // the rejection loops of activeUE make the glibc stream position data dependent
     }
     HIPCHK(hipSetDevice(e->device));
     auto t0 = std::chrono::steady_clock::now();
     e->last = prach_timing{};
     double kernel_ms = 0, upload_ms = 0;
+    { // NOMA.c variant: its own kernel
+        std::vector<int> idx;
+        for (int k = 0; k < n; k++)
+            if (cfgs[k].variant == PRACH_VARIANT_NOMA_C) idx.push_back(k);
+        if (!idx.empty()) {
+            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, 0, kernel_ms, upload_ms);
+            if (rc != PRACH_OK) return rc;
+        }
+    }
     for (int mode = 0; mode < 2; mode++) {
         std::vector<int> idx;
         for (int k = 0; k < n; k++)
-            if (cfgs[k].rng_mode == mode) idx.push_back(k);
+            if (cfgs[k].rng_mode == mode && cfgs[k].variant != PRACH_VARIANT_NOMA_C) idx.push_back(k);
         if (idx.empty()) continue;
         bool cluster_ok = mode == PRACH_RNG_PHILOX && !e->opt_legacy;
         for (int k : idx) cluster_ok = cluster_ok && cfgs[k].nUE <= (1 << 20); // dead-group bitmap / header granule limits

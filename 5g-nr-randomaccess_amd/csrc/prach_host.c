@@ -34,6 +34,13 @@ void prach_cfg_defaults(prach_cfg *c, int variant) {
     c->cellRadius = 400.0f;
     c->hBS = 10.0f;
     c->hUT = 1.8f;
+    if (variant == PRACH_VARIANT_NOMA_C) { /* NOMA.c:41-57 */
+        c->nGrantUL = 2;        /* per sector */
+        c->maxRarWindow = 5;
+        c->maxMsg2TxCount = 10; /* maxMsg1ReTx */
+        c->cellRadius = 500.0f;
+        c->rng_mode = PRACH_RNG_PHILOX;
+    }
 }
 
 int prach_cfg_validate(const prach_cfg *c) {
@@ -119,6 +126,66 @@ void prach_glibc_stream(uint32_t seed, uint64_t first, uint64_t n, int32_t *out)
         if (++f == 31) f = 0;
         if (++b == 31) b = 0;
     }
+}
+
+/* ---- NOMA.c activation table ---------------------------------------------------------------- */
+static uint32_t philox31(uint64_t seed, uint32_t nUE, uint32_t variant, uint32_t ue, uint32_t k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t c0 = ue, c1 = k, c2 = nUE, c3 = variant, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0 >> 1;
+}
+
+int prach_noma_activation_table(const prach_cfg *c, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
+                                uint32_t *ndraws) {
+    if (!c || !preamble0 || !sector || !gain || !lgain || !ndraws) return PRACH_ERR_ARG;
+    const float pi = 3.14; /* NOMA.c:55 */
+    const float cellRadius = c->cellRadius;
+    for (int i = 0; i < c->nUE; i++) {
+        uint32_t k = 0;
+#define DRAW() ((int)philox31(c->seed, (uint32_t)c->nUE, PRACH_VARIANT_NOMA_C, (uint32_t)i, k++))
+        preamble0[i] = DRAW() % c->nPreamble; /* NOMA.c:133 */
+        float angle = (float)DRAW() / (float)(2147483647) * 2 * pi; /* NOMA.c:142 */
+        int sec;
+        if (angle >= 0 && angle < ((1. / 3.) * pi)) sec = 0; /* NOMA.c:146-163 */
+        else if (angle >= ((1. / 3.) * pi) && angle < ((2. / 3.) * pi)) sec = 1;
+        else if (angle >= ((2. / 3.) * pi) && angle < 3.14) sec = 2;
+        else if (angle >= pi && angle < ((4. / 3.) * pi)) sec = 3;
+        else if (angle >= ((4. / 3.) * pi) && angle < ((5. / 3.) * pi)) sec = 4;
+        else sec = 5;
+        sector[i] = sec;
+        float r;
+        while (1) { /* NOMA.c:167-172 */
+            r = cellRadius * sqrt((float)DRAW() / (float)2147483647);
+            if (r > 35.0) break;
+        }
+        float x = r * cos(angle), y = r * sin(angle), pathloss; /* NOMA.c:176-178 */
+        double env = sqrt(x * x + y * y);
+        double ch_g = 0, rayleigh;
+        while (ch_g < 1e-7) { /* NOMA.c:185-189 */
+            pathloss = sqrt(1 + pow(env, 2));
+            rayleigh = sqrt(-2 * log((double)DRAW() / (double)2147483647));
+            ch_g = pow(rayleigh / pathloss, 2);
+        }
+#undef DRAW
+        gain[i] = ch_g;
+        lgain[i] = log(ch_g);
+        ndraws[i] = k;
+    }
+    return PRACH_OK;
+}
+
+size_t prach_format_noma_line(const prach_cfg *c, const prach_result *r, char *buf, size_t cap) {
+    char tmp[256];
+    int n = snprintf(tmp, sizeof tmp, "%d %d %lf %lf %lf\n", c->nUE, r->nSuccessUE, ((float)r->nSuccessUE / (float)c->nUE) * 100.0,
+                     ((float)r->preambleTxCount / (float)r->nSuccessUE), ((float)(int)r->sumTimer / (float)r->nSuccessUE));
+    if (buf && (size_t)n < cap) memcpy(buf, tmp, (size_t)n + 1);
+    return (size_t)n;
 }
 
 /* ---- text surfaces ---------------------------------------------------------------------------- */

@@ -61,7 +61,8 @@ typedef struct prach_cfg {
                                the nUE sweep: Beta.c:66-71) */
     int32_t max_steps;      /* 0 = run to maxTime; >0 = stop after that many subframes */
     int32_t reserved;
-    float cellRadius, hBS, hUT; /* parsed by the CLI, never read by the simulation (WithNOMA:80-82) */
+    float cellRadius, hBS, hUT; /* parsed by the CLI, never read by the simulation (WithNOMA:80-82);
+                                   NOMA_C: cellRadius scales the UE drop (NOMA.c:56,168) */
 } prach_cfg;
 
 typedef struct prach_result {
@@ -122,6 +123,16 @@ int prach_arrival_schedule(const prach_cfg *cfg, int32_t *out, int cap, int32_t 
 /* k-th .. k+n-th values of srand(seed)/rand() */
 void prach_glibc_stream(uint32_t seed, uint64_t first, uint64_t n, int32_t *out);
 const char *prach_strerror(int status);
+
+/* NOMA.c variant (PRACH_VARIANT_NOMA_C): per-UE attributes fixed at activation (activeUE, NOMA.c:131-192):
+ * first preamble, sector, Rayleigh channel gain and its natural log (the pairing test of NOMA.c:276 uses
+ * 10*log(high)-10*log(low)), and the number of draws the activation consumed.  The double-precision
+ * libm work (cos, sin, log, pow) runs ONCE per UE here on the host, with the same libm the reference links,
+ * so the device-side sort / pairing is bit-identical to the reference; the per-subframe loop is on the GPU.
+ * Philox mode only (draw k of UE i; the rejection loops make the glibc stream position data dependent). */
+int prach_noma_activation_table(const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
+                                uint32_t *ndraws);
+size_t prach_format_noma_line(const prach_cfg *, const prach_result *, char *buf, size_t cap); /* NOMA.c:606-632 */
 
 /* Text surfaces, byte-compatible with the reference (latency values excepted) */
 size_t prach_format_logs(const prach_ue_log *ue, int nUE, char *buf, size_t cap);           /* Beta.c:501 */

@@ -173,3 +173,52 @@ def model_run_trial(cfg: OracleCfg, rng_mode, seed, stream=None, stream_off=0, n
     if rc != 0:
         raise RuntimeError(f"model_run_trial rc={rc}")
     return res, ues
+
+
+# ---- NOMA.c variant ---------------------------------------------------------------------------------
+
+class NomaCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nUE", "nPreamble", "backoff", "nGrantUL", "maxRarWindow", "maxMsg1ReTx",
+                                         "accessTime", "max_steps")] + [("cellRadius", C.c_float)]
+
+
+class NomaResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nSuccessUE", "delay", "nTxP", "activeCheck", "time_exit", "raFailedUEs")] + [
+        ("draws", C.c_uint64), ("steps", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+NOMA_UE_FIELDS = ("idx", "timer", "active", "txTime", "firstTxTime", "secondTxTime", "nowBackoff", "preamble", "sector",
+                  "rarWindow", "msg1ReTx", "nTxPreamble", "msg2", "msg3Wait", "RA", "RaFailed")
+
+
+class NomaUE(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in NOMA_UE_FIELDS] + [("channelGain", C.c_double)]
+
+
+def make_noma_cfg(nUE, nPreamble=54, backoff=20, nGrantUL=2, maxRarWindow=5, maxMsg1ReTx=10, accessTime=5, max_steps=0,
+                  cellRadius=500.0) -> NomaCfg:
+    return NomaCfg(nUE, nPreamble, backoff, nGrantUL, maxRarWindow, maxMsg1ReTx, accessTime, max_steps, cellRadius)
+
+
+def noma_run_trial(cfg: NomaCfg, rng: Rng, want_ues=True):
+    L = lib()
+    L.noma_oracle_run_trial.restype = C.c_int
+    L.noma_oracle_run_trial.argtypes = [C.POINTER(NomaCfg), C.c_void_p, C.POINTER(NomaResult), C.POINTER(NomaUE)]
+    res = NomaResult()
+    ues = (NomaUE * cfg.nUE)() if want_ues else None
+    rc = L.noma_oracle_run_trial(C.byref(cfg), rng.h, C.byref(res), ues)
+    if rc != 0:
+        raise RuntimeError(f"noma_oracle_run_trial rc={rc}")
+    return res, ues
+
+
+def noma_format_line(cfg, res) -> bytes:
+    L = lib()
+    L.noma_format_result_line.restype = C.c_size_t
+    L.noma_format_result_line.argtypes = [C.POINTER(NomaCfg), C.POINTER(NomaResult), C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(256)
+    n = L.noma_format_result_line(C.byref(cfg), C.byref(res), buf, 256)
+    return buf.raw[:n]

@@ -23,12 +23,7 @@
 
 #define betaF 0.0165 /* Beta.c:8 (note: not 1/B(3,4); kept as is) */
 
-struct oracle_rng {
-    int mode;
-    uint64_t seed;
-    glibc_rand_t g;
-    uint64_t consumed;
-};
+#include "oracle_internal.h"
 
 oracle_rng *oracle_rng_new(int mode, uint64_t seed) {
     oracle_rng *r = (oracle_rng *)calloc(1, sizeof(*r));

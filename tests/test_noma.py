@@ -1,0 +1,93 @@
+"""NOMA.c variant (sector power-level grouping, SURVEY §8 a13 / BASELINE config 4).
+CPU: the oracle against the real NOMA program's output (glibc stream, chained sweep) and the host-side
+activation table against the oracle.  GPU (-m gpu): the HIP kernel against the oracle in Philox mode."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def golden_lines():
+    g = load_golden("noma_c")
+    seeds, cur = [], []
+    for l in g["stdout"].split("\n"):
+        if l == "Done":
+            seeds.append(cur)
+            cur = []
+        elif l:
+            cur.append(l)
+    return g, seeds
+
+
+def test_noma_oracle_reproduces_reference_stdout(ob):
+    """Pinned: the 'nUE nSucc succ% avgTx avgDelay' lines NOMA.c prints (NOMA.c:606-632), chained over the sweep."""
+    g, seeds = golden_lines()
+    assert len(seeds) == 10 and all(len(s) == 10 for s in seeds)
+    assert seeds[0] == seeds[1]  # glibc: srand(0) == srand(1)
+    for seed, upto in ((0, 40000), (2, 20000)):
+        rng = ob.Rng(ob.RNG_GLIBC, seed)
+        for k, n in enumerate(range(10000, upto + 1, 10000)):
+            cfg = ob.make_noma_cfg(n)
+            res, _ = ob.noma_run_trial(cfg, rng, want_ues=False)
+            assert ob.noma_format_line(cfg, res).decode().strip() == seeds[seed][k], (seed, n)
+    # the per-nUE files are the same lines appended seed after seed (mode "aw+", NOMA.c:605)
+    assert g["files"]["Sector_10000_Result.txt"].split("\n")[0] == seeds[0][0]
+
+
+def test_noma_activation_table_matches_oracle(pkg, ob):
+    """prach_noma_activation_table (host C, same libm) == what the oracle's activeUE computes, bit for bit."""
+    n, seed = 6000, 3
+    cfg = pkg.make_cfg(n, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=seed)
+    assert (cfg.nGrantUL, cfg.maxRarWindow, cfg.maxMsg2TxCount, cfg.accessTime, cfg.nPreamble, cfg.backoff) == (2, 5, 10, 5, 54, 20)  # NOMA.c:41-47
+    pre0, sec, gain, lgain, nd = pkg.noma_activation_table(cfg)
+    res, ues = ob.noma_run_trial(ob.make_noma_cfg(n), ob.Rng(ob.RNG_PHILOX, seed))
+    a = np.frombuffer(ues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))
+    act = a["i"][:, 8] >= 0  # activated UEs have a sector
+    assert act.sum() == res.activeCheck == n
+    assert (a["i"][:, 8] == sec).all()
+    assert (a["g"] == gain).all()
+    assert (np.log(gain) == lgain).all() and (gain >= 1e-7).all() and (nd >= 4).all()
+    assert sec.min() >= 0 and sec.max() <= 5 and pre0.min() >= 0 and pre0.max() < 54
+
+
+NOMA_GPU_CASES = [(3000, 0, {}), (10000, 1, {}), (30000, 2, {}), (64, 3, {}), (1, 4, {}), (5000, 5, dict(nPreamble=8, backoff=3)),
+                  (8000, 6, dict(nGrantUL=1, maxMsg2TxCount=3)), (8000, 7, dict(nPreamble=64, nGrantUL=5, backoff=40))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nUE,seed,kw", NOMA_GPU_CASES)
+def test_gpu_noma_equals_oracle(pkg, ob, engine, nUE, seed, kw):
+    cfg = pkg.make_cfg(nUE, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=seed, **kw)
+    (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+    okw = dict(kw)
+    if "maxMsg2TxCount" in okw:
+        okw["maxMsg1ReTx"] = okw.pop("maxMsg2TxCount")
+    ocfg = ob.make_noma_cfg(nUE, **okw)
+    ores, oues = ob.noma_run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, seed))
+    assert res.status == 0
+    assert (res.nSuccessUE, res.sumTimer, res.preambleTxCount, res.failCounts, res.activeCheck, res.draws) == \
+           (ores.nSuccessUE, ores.delay, ores.nTxP, ores.raFailedUEs, ores.activeCheck, ores.draws)
+    a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16)
+    b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
+    diff = np.where((a != b).any(axis=1))[0]
+    assert diff.size == 0, (diff[:5], a[diff[:3]], b[diff[:3]])
+    if res.nSuccessUE:
+        assert pkg.format_noma_line(cfg, res) == ob.noma_format_line(ocfg, ores)
+
+
+@pytest.mark.gpu
+def test_gpu_noma_full_size_and_statistics(pkg, ob, engine):
+    """BASELINE config 4: nUE=100 000; bit-exact vs the oracle, and statistically consistent with the reference's
+    glibc-stream run (26 884 successes at seed 0, tests/golden/noma_c.json) — different RNG, same process."""
+    cfg = pkg.make_cfg(100000, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=0)
+    (res,), _ = engine.run_trials([cfg])
+    ores, _ = ob.noma_run_trial(ob.make_noma_cfg(100000), ob.Rng(ob.RNG_PHILOX, 0), want_ues=False)
+    assert (res.nSuccessUE, res.sumTimer, res.preambleTxCount, res.failCounts, res.draws) == \
+           (ores.nSuccessUE, ores.delay, ores.nTxP, ores.raFailedUEs, ores.draws)
+    assert abs(res.nSuccessUE - 26884) < 600
+    bad = pkg.make_cfg(1000, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_GLIBC)
+    with pytest.raises(pkg.PrachError) as ei:
+        engine.run_trials([bad])
+    assert ei.value.status == -2
