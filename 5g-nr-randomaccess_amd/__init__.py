@@ -101,6 +101,9 @@ def lib():
         L.prach_noma_activation_table.argtypes = [C.POINTER(PrachCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.prach_format_noma_line.argtypes = [C.POINTER(PrachCfg), C.POINTER(PrachResult), C.c_char_p, C.c_size_t]
         L.prach_format_noma_line.restype = C.c_size_t
+        L.prach_results_csv_accumulate.argtypes = [C.POINTER(C.c_double), C.c_char_p]
+        L.prach_results_csv_row.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_char_p, C.c_size_t]
+        L.prach_results_csv_row.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -108,7 +111,8 @@ def lib():
 EXPORTS = ("prach_engine_create", "prach_engine_destroy", "prach_engine_set", "prach_run_trials", "prach_last_timing",
            "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_arrival_schedule", "prach_glibc_stream",
            "prach_strerror", "prach_format_logs", "prach_format_results", "prach_format_stdout",
-           "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line")
+           "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line",
+           "prach_results_csv_accumulate", "prach_results_csv_row")
 
 
 def make_cfg(nUE, variant=VARIANT_BETA_C, uniform=0, rng_mode=RNG_GLIBC, seed=0, stream_offset=0, **kw) -> PrachCfg:
@@ -221,3 +225,18 @@ def format_noma_line(cfg, res) -> bytes:
     buf = C.create_string_buffer(256)
     n = lib().prach_format_noma_line(C.byref(cfg), C.byref(res), buf, 256)
     return buf.raw[:n]
+
+
+def results_csv(rows_of_results_texts):
+    """results.csv bytes for [[Results.txt text of seed 0, seed 1, ...] per nUE point] (AveragePerformance.py)."""
+    out = b""
+    for texts in rows_of_results_texts:
+        acc = (C.c_double * 6)()
+        for t in texts:
+            rc = lib().prach_results_csv_accumulate(acc, t if isinstance(t, bytes) else t.encode())
+            if rc != OK:
+                raise PrachError(rc, "(prach_results_csv_accumulate)")
+        buf = C.create_string_buffer(512)
+        n = lib().prach_results_csv_row(acc, len(texts), buf, 512)
+        out += buf.raw[:n]
+    return out

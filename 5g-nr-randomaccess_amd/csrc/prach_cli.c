@@ -7,7 +7,11 @@
  * -bs, -ut) and the ones README.md documents (-r, -m, -u) are taken; `-d 2` selects Beta as the
  * README says (the reference's validation rejects it).
  *
- * Extensions (not in the reference): --program beta|withnoma, --rng glibc|philox, --nue N,
+ * `--program noma` runs NOMA.c's loop instead (NOMA.c:644-717: 10 seeds by default, one result line per
+ * (seed, nUE) on stdout and appended to TestResults/Sector_{nUE}_Result.txt, "Done" per seed); that
+ * variant draws from Philox (the reference's rand() stream position is data dependent there).
+ *
+ * Extensions (not in the reference): --program beta|withnoma|noma, --rng glibc|philox, --nue N,
  * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N.
  */
 #define _GNU_SOURCE
@@ -16,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
 
 static void usage_and_exit(void) { /* text of WithNOMA:160-202 */
@@ -66,9 +71,11 @@ int main(int argc, char *argv[]) {
     const char *outdir = ".";
     /* --program must be known before the defaults are laid down */
     for (int i = 1; i + 1 < argc; i += 2)
-        if (strcmp(argv[i], "--program") == 0) variant = strcmp(argv[i + 1], "beta") == 0 ? PRACH_VARIANT_BETA_C : PRACH_VARIANT_WITHNOMA_C;
+        if (strcmp(argv[i], "--program") == 0)
+            variant = strcmp(argv[i + 1], "beta") == 0 ? PRACH_VARIANT_BETA_C : (strcmp(argv[i + 1], "noma") == 0 ? PRACH_VARIANT_NOMA_C : PRACH_VARIANT_WITHNOMA_C);
     prach_cfg base;
     prach_cfg_defaults(&base, variant);
+    if (variant == PRACH_VARIANT_NOMA_C) { randomMax = 10; rng = PRACH_RNG_PHILOX; want_logs = 0; } /* NOMA.c:644 */
 
     for (int i = 1; i < argc; i += 2) {
         const char *a = argv[i];
@@ -128,6 +135,34 @@ int main(int argc, char *argv[]) {
         }
     }
     base.rng_mode = rng;
+
+    if (variant == PRACH_VARIANT_NOMA_C) { /* NOMA.c main: no banner, one line per trial, "Done" per seed */
+        prach_engine *eng = NULL;
+        int rc = prach_engine_create(device, &eng);
+        if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+        char line[256], path[1024];
+        snprintf(path, sizeof path, "%s/TestResults", outdir);
+        mkdir(path, 0755);
+        for (int seed = 0; seed < randomMax; seed++) {
+            for (int n = sweep_lo; n <= sweep_hi; n += sweep_step) {
+                prach_cfg c = base;
+                c.nUE = n; c.seed = (uint64_t)seed; c.rng_mode = PRACH_RNG_PHILOX;
+                prach_result r;
+                rc = prach_run_trials(eng, &c, 1, &r, NULL);
+                if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+                prach_format_noma_line(&c, &r, line, sizeof line);
+                fputs(line, stdout);
+                snprintf(path, sizeof path, "%s/TestResults/Sector_%d_Result.txt", outdir, n); /* NOMA.c:603-605 */
+                FILE *fp = fopen(path, "a");
+                if (!fp) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(PRACH_ERR_IO)); return 2; }
+                fputs(line, fp);
+                fclose(fp);
+            }
+            printf("Done\n"); /* NOMA.c:716 */
+        }
+        prach_engine_destroy(eng);
+        return 0;
+    }
 
     if (base.uniform) printf("Traffic model: Uniform\n\n"); /* WithNOMA:208-213 */
     else printf("Traffic model: Beta\n\n");

@@ -105,7 +105,7 @@ template <bool FINAL>
 __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, const Ctx &C, const FastMods &FM, const int t, const int prevAC,
                                              const int activeCheck, int *mbev) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nP = P.nP, aT = P.aT, nUE = P.nUE;
+    const int aT = P.aT, nUE = P.nUE;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
     const int ngroups = (activeCheck + 63) >> 6;
     const int tp = t - 1;

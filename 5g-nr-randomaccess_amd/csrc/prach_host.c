@@ -307,3 +307,74 @@ int prach_write_trial_files(const prach_cfg *c, const prach_result *r, const pra
     }
     return rc;
 }
+
+/* ---- results.csv (AveragePerformance.py) ------------------------------------------------------ */
+
+int prach_results_csv_accumulate(double acc[6], const char *txt) {
+    if (!acc || !txt) return PRACH_ERR_ARG;
+    const char *p = txt;
+    for (int i = 0; i < 6; i++) { /* data.append(float(line.strip())) for the six lines (AveragePerformance.py:14-19) */
+        char *end;
+        double v = strtod(p, &end);
+        if (end == p) return PRACH_ERR_ARG;
+        acc[i] += v;
+        p = end;
+        while (*p == '\n' || *p == '\r' || *p == ' ') p++;
+    }
+    return PRACH_OK;
+}
+
+/* Python's repr(float): shortest digit string that round-trips, fixed notation for 1e-4 <= |x| < 1e16 */
+static int py_float_repr(double x, char *out, size_t cap) {
+    if (x == 0) return snprintf(out, cap, signbit(x) ? "-0.0" : "0.0");
+    if (!isfinite(x)) return snprintf(out, cap, isnan(x) ? "nan" : (x > 0 ? "inf" : "-inf"));
+    char e[40];
+    int prec;
+    for (prec = 1; prec <= 17; prec++) {
+        snprintf(e, sizeof e, "%.*e", prec - 1, x);
+        if (strtod(e, NULL) == x) break;
+    }
+    /* e = [-]d.ddddde[+-]XX */
+    const char *m = e;
+    int neg = 0;
+    if (*m == '-') { neg = 1; m++; }
+    char digits[24];
+    int nd = 0;
+    for (; *m && *m != 'e'; m++)
+        if (*m >= '0' && *m <= '9') digits[nd++] = *m;
+    while (nd > 1 && digits[nd - 1] == '0') nd--; /* shortest */
+    int ex = atoi(m + 1);
+    char body[64];
+    int n = 0;
+    if (ex < -4 || ex >= 16) {
+        body[n++] = digits[0];
+        if (nd > 1) { body[n++] = '.'; for (int i = 1; i < nd; i++) body[n++] = digits[i]; }
+        n += snprintf(body + n, sizeof body - n, "e%c%02d", ex < 0 ? '-' : '+', ex < 0 ? -ex : ex);
+    } else if (ex >= 0) {
+        for (int i = 0; i <= ex; i++) body[n++] = i < nd ? digits[i] : '0';
+        body[n++] = '.';
+        if (nd > ex + 1) for (int i = ex + 1; i < nd; i++) body[n++] = digits[i];
+        else body[n++] = '0';
+    } else {
+        body[n++] = '0'; body[n++] = '.';
+        for (int i = 0; i < -ex - 1; i++) body[n++] = '0';
+        for (int i = 0; i < nd; i++) body[n++] = digits[i];
+    }
+    body[n] = 0;
+    return snprintf(out, cap, "%s%s", neg ? "-" : "", body);
+}
+
+size_t prach_results_csv_row(const double acc[6], int nseeds, char *buf, size_t cap) {
+    char tmp[512];
+    int n = 0;
+    for (int i = 0; i < 6; i++) {
+        double v = acc[i] / (double)nseeds;       /* lists/len(seedNumber) */
+        v = rint(v * 1000.0) / 1000.0;             /* np.around(., 3): multiply, rint (half to even), divide */
+        char f[64];
+        py_float_repr(v, f, sizeof f);
+        n += snprintf(tmp + n, sizeof tmp - n, "%s%s", i ? "," : "", f);
+    }
+    n += snprintf(tmp + n, sizeof tmp - n, "\r\n"); /* csv.writer default line terminator */
+    if (buf && (size_t)n < cap) memcpy(buf, tmp, (size_t)n + 1);
+    return (size_t)n;
+}

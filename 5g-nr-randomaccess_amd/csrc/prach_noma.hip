@@ -24,7 +24,7 @@ namespace prach {
 namespace {
 
 // packed word of the NOMA record
-constexpr unsigned N_ACT_SHIFT = 0, N_RA_BIT = 1u << 2, N_FAIL_BIT = 1u << 3, N_MSG2_BIT = 1u << 4, N_M3W_BIT = 1u << 5,
+constexpr unsigned N_RA_BIT = 1u << 2, N_FAIL_BIT = 1u << 3, N_MSG2_BIT = 1u << 4, N_M3W_BIT = 1u << 5,
                    N_PRE_SHIFT = 6, N_RETX_SHIFT = 14;
 constexpr int NOMA_VARIANT = 2;
 

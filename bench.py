@@ -191,14 +191,23 @@ def main():
             cfg = pkg.make_cfg(args.nue, variant=pkg.VARIANT_WITHNOMA_C, rng_mode=pkg.RNG_PHILOX, seed=0)
             (r,), _ = eng.run_trials([cfg])
             extras["withnoma_g12_single_trial_kernel_updates_per_s"] = args.nue * r.steps / (eng.timing().kernel_ms * 1e-3)
-            # (3) batched: BASELINE config 3 shape — nUE sweep 10k..100k x 8 seeds concurrently (HBM-bound regime)
+            # (3) BASELINE config 3: nUE sweep 10k..100k x --times 100, all 1000 trials concurrently (one workgroup per
+            #     trial): the regime where the state of the in-flight trials streams through HBM every subframe
             cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_WITHNOMA_C, rng_mode=pkg.RNG_PHILOX, seed=s)
-                    for s in range(8) for n in range(10000, 100001, 10000)]
+                    for s in range(100) for n in range(10000, 100001, 10000)]
             rs, _ = eng.run_trials(cfgs)
             upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
             kms = eng.timing().kernel_ms
-            extras["batched_sweep_80_trials"] = {"kernel_updates_per_s": upd / (kms * 1e-3), "kernel_ms": kms,
-                                                 "algorithmic_GBs": 32.0 * upd / (kms * 1e-3) / 1e9}
+            extras["config3_sweep_x100_1000_trials"] = {
+                "kernel_updates_per_s": upd / (kms * 1e-3), "kernel_ms": kms, "updates": upd,
+                "roofline": {"bound": "hbm", "achieved": 32.0 * upd / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 32.0 * upd / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "mean_success_ratio_100k": sum(r_.nSuccessUE for c, r_ in zip(cfgs, rs) if c.nUE == 100000) / 100 / 1e5}
+            # (4) BASELINE config 4: NOMA.c power-level grouping, nUE=100 000, one trial
+            cfg = pkg.make_cfg(args.nue, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=0)
+            (r,), _ = eng.run_trials([cfg])
+            extras["noma_c_single_trial"] = {"kernel_updates_per_s": args.nue * r.steps / (eng.timing().kernel_ms * 1e-3),
+                                             "nSuccessUE": r.nSuccessUE, "upload_ms_activation_table": eng.timing().upload_ms}
             out["extras"] = extras
         if world == 1 and not args.no_cpu:
             from oracle import binding as ob

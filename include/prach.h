@@ -142,6 +142,13 @@ int prach_result_file_name(const prach_cfg *, int is_log, char *buf, size_t cap)
 int prach_write_trial_files(const prach_cfg *, const prach_result *, const prach_ue_log *ue, double latency_s,
                             const char *root_dir);
 
+/* results.csv (AveragePerformance.py:7-24): per nUE point the six lines of every seed's Beta.c Results.txt
+ * are summed in seed order (Python floats = doubles), divided by the number of seeds, rounded with
+ * np.around(x, 3) and written by csv.writer (shortest float repr, CRLF line ends, no header).
+ * prach_results_csv_accumulate adds one Results.txt text to acc[6]; prach_results_csv_row formats one row. */
+int prach_results_csv_accumulate(double acc[6], const char *results_txt);
+size_t prach_results_csv_row(const double acc[6], int nseeds, char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,18 @@
+"""Development probe: batched sweep throughput (BASELINE config 3 shape). Not a test."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+m = g.load_package()
+eng = m.Engine(0)
+times = int(sys.argv[1]) if len(sys.argv) > 1 else 26
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+eng.set("cluster", G)
+cfgs = [m.make_cfg(n, variant=variant, rng_mode=m.RNG_PHILOX, seed=s) for s in range(times) for n in range(10000, 100001, 10000)]
+t0 = time.time()
+res, _ = eng.run_trials(cfgs)
+wall = time.time() - t0
+tm = eng.timing()
+upd = sum(c.nUE * r.steps for c, r in zip(cfgs, res))
+print(f"trials={len(cfgs)} variant={variant} G={G} launches={tm.launches} wgs={tm.workgroups} kernel={tm.kernel_ms:.1f}ms wall={wall:.2f}s updates={upd:.3e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} algoGB/s={32*upd/(tm.kernel_ms*1e-3)/1e9:.0f} bad={sum(r.status!=0 for r in res)}")

@@ -120,3 +120,37 @@ def test_cli_usage_on_unknown_flag(pkg):
     assert "--hut           -u : Height of UE from ground (float)" in p.stdout
     p = subprocess.run([pkg.CLI_PATH, "-t"], capture_output=True, text=True)  # the reference segfaults here
     assert p.returncode == 255
+
+
+def test_results_csv_matches_numpy_csv_writer(pkg, tmp_path):
+    """results.csv rows == what AveragePerformance.py's arithmetic and csv.writer produce
+    (sequential double sum in seed order, /nseeds, np.around(.,3), float repr, CRLF)."""
+    import csv
+    import io
+    import random
+
+    import numpy as np
+    rnd = random.Random(7)
+    rows = []
+    for nue in range(10000, 100001, 10000):
+        texts = []
+        for s in range(100):
+            succ = rnd.randint(0, nue)
+            texts.append("%d\n%.2lf\n%d\n%.2lf\n%.2lf\n%lf" % (nue, 100.0 * succ / nue, succ, rnd.uniform(1, 8), rnd.uniform(15, 120),
+                                                               rnd.uniform(0.1, 1600)))
+        rows.append(texts)
+    mine = pkg.results_csv(rows)
+    avg = [[0, 0, 0, 0, 0, 0] for _ in rows]
+    for n, texts in enumerate(rows):
+        for t in texts:
+            data = [float(l.strip()) for l in t.split("\n")]
+            for i in range(6):
+                avg[n][i] += data[i]
+    buf = io.StringIO(newline="")
+    w = csv.writer(buf)
+    for lists in np.array(avg):
+        w.writerow(np.around(lists / 100, 3))
+    assert mine == buf.getvalue().encode()
+    # the shape of the reference's own file (results.csv:1): trailing zeros dropped, ".0" kept
+    ref_like = pkg.results_csv([["10000\n100.00\n10000\n2.59\n47.11\n2.242"] * 4])
+    assert ref_like == b"10000.0,100.0,10000.0,2.59,47.11,2.242\r\n"
