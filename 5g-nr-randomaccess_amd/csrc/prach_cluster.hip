@@ -89,21 +89,48 @@ __device__ __forceinline__ void st_sc1_64(long long *p, long long v) { __hip_ato
 
 struct FastMods { FastMod nP, backoff, aT, five; };
 
+// Event info word (20 bits): type[2:0] ispre[3] bucket p[11:4] old bucket q[19:12].
+// Exchange granule: ONE naturally aligned 8-byte write-through store {20-bit value | tag[11:0]} {20-bit value | tag[15:12]}.
+// Every granule carries the subframe tag (t+1 <= 60001 fits 16 bits), so it validates itself: the consumer
+// re-reads until the tag matches — no drain, no flag, no fence (cdna_hip_programming.md G16, R2).
+constexpr unsigned GR_NONE = 0xFFFFFu;
+__device__ __forceinline__ long long mk_granule(unsigned lo20, unsigned hi20, unsigned tag) {
+    const unsigned w0 = (lo20 & 0xFFFFFu) | ((tag & 0xFFFu) << 20), w1 = (hi20 & 0xFFFFFu) | (((tag >> 12) & 0xFu) << 20);
+    return (long long)(((unsigned long long)w1 << 32) | w0);
+}
+__device__ __forceinline__ bool granule_ok(long long g, unsigned tag) {
+    const unsigned w0 = (unsigned)g, w1 = (unsigned)((unsigned long long)g >> 32);
+    return (w0 >> 20) == (tag & 0xFFFu) && ((w1 >> 20) & 0xFu) == ((tag >> 12) & 0xFu);
+}
+// bounded re-read of one granule until it carries `tag`
+__device__ __forceinline__ long long wait_granule(const long long *p, unsigned tag, int *status_word) {
+    long long g = ld_sc1_64(p);
+    unsigned spins = 0;
+    while (!granule_ok(g, tag)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) { *status_word = PRACH_ERR_INTERNAL; break; }
+        g = ld_sc1_64(p);
+    }
+    return g;
+}
+
 struct Ctx {
     int b, G, evw, mbstride;
-    int *mbox;      // [2][G][mbstride]
+    int *mbox;      // [2][G][mbstride ints]: per workgroup 1 header + nP bucket + evw event granules
     unsigned *bar;  // monotonic arrival counter of this trial
     int2 *cand;     // this workgroup's private early-leaver candidate scratch
 };
 
-__device__ __forceinline__ int *mb_of(const Ctx &C, int parity, int wg) { return C.mbox + ((size_t)parity * C.G + wg) * C.mbstride; }
+__device__ __forceinline__ long long *gr_of(const Ctx &C, int parity, int wg) {
+    return reinterpret_cast<long long *>(C.mbox + ((size_t)parity * C.G + wg) * C.mbstride);
+}
 
 // ---------------------------------------------------------------------------------------------
 // pass over the groups this workgroup owns.  FINAL: only the deferred apply of the last subframe.
 // ---------------------------------------------------------------------------------------------
 template <bool FINAL>
 __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, const Ctx &C, const FastMods &FM, const int t, const int prevAC,
-                                             const int activeCheck, int *mbev) {
+                                             const int activeCheck, long long *mbev, const unsigned tag) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int aT = P.aT, nUE = P.nUE;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
@@ -282,8 +309,9 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
                 if (evtype != 0) {
                     const int slot = base + __popcll(em & lanemask_lt(lane));
                     const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
-                    if (slot < C.evw) st_sc1_64(reinterpret_cast<long long *>(mbev) + slot,
-                                                (long long)(unsigned)i | ((long long)(evtype | (ispre << 3) | (evp << 8) | (evq << 16)) << 32));
+                    const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
+                    if (C.G == 1) { if (slot < EVCAPC) L.gev[slot] = make_int2(i, info); }
+                    else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)i, (unsigned)info, tag));
                 }
             }
             const unsigned long long cm = __ballot(eclass);
@@ -343,7 +371,7 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, const in
         int cancelled = 0;
         for (int s_ = 0; s_ < m; s_++) {
             const int idx = __builtin_amdgcn_readlane(cidx, s_), info = __builtin_amdgcn_readlane(cinfo, s_);
-            const int p = (info >> 8) & 0xff, q = (info >> 16) & 0xff;
+            const int p = (info >> 4) & 0xff, q = (info >> 12) & 0xff;
             if (fc_get(f0, f1, f2, f3, q) < idx) { // bumped before its turn: does not re-join
                 if (lane == s_) cancelled = 1;
             } else if (idx < fc_get(f0, f1, f2, f3, p)) { // its call becomes the first one on p
@@ -410,10 +438,11 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         const int prevAC = activeCheck;
         if (t % aT == 0 && activeCheck != nUE) activeCheck = P.sched[t / aT]; // Beta.c:121-134
         const int parity = t & 1;
-        int *const mymb = mb_of(C, parity, b);
-        int *const mbev = mymb + 4 + 2 * nP;
+        const unsigned tag = (unsigned)(t + 1);
+        long long *const mygr = G > 1 ? gr_of(C, parity, b) : nullptr;
+        long long *const mbev = G > 1 ? mygr + 1 + nP : nullptr;
 
-        cluster_pass<false>(P, L, C, FM, t, prevAC, activeCheck, mbev);
+        cluster_pass<false>(P, L, C, FM, t, prevAC, activeCheck, mbev, tag);
         __syncthreads();
         STAMP(0);
 
@@ -423,88 +452,82 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             const int2 c = C.cand[k];
             if (c.x < L.mloc[c.y]) {
                 const int slot = atomicAdd(&L.scal[C_NEV], 1);
-                if (slot < C.evw) st_sc1_64(reinterpret_cast<long long *>(mbev) + slot, (long long)(unsigned)c.x | ((long long)(EVC_LEAVER | (c.y << 8)) << 32));
+                const int info = EVC_LEAVER | (c.y << 4);
+                if (G == 1) { if (slot < EVCAPC) L.gev[slot] = make_int2(c.x, info); }
+                else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)c.x, (unsigned)info, tag));
             }
         }
         __syncthreads();
-        // publish: histogram, lowest caller per bucket, header; then — after every storing wave has drained its
-        // write-through stores and the workgroup has met — ONE lane stores the tag (t+1) the consumers poll.
-        unsigned long long hdr;
-        {
+        int N;
+        if (G == 1) {
+            // one workgroup owns the whole trial: its histogram / lowest callers ARE the totals; events are in LDS
             const int nevraw = L.scal[C_NEV];
-            for (int k = tid; k < nP; k += WG_THREADS) { st_sc1(mymb + 4 + k, L.hist[k]); st_sc1(mymb + 4 + nP + k, L.mloc[k]); }
-            hdr = (unsigned long long)(unsigned)(t + 1) | ((unsigned long long)(unsigned)min(nevraw, C.evw) << 16) |
-                  ((unsigned long long)(nevraw > C.evw ? 1u : 0u) << 39) | ((unsigned long long)(unsigned)L.scal[C_NSUCC] << 40);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // ONE 8-byte write-through store publishes {tag = t+1, #events, overflow, #successes so far}
-        if (tid == 0) st_sc1_64(reinterpret_cast<long long *>(mymb), (long long)hdr);
-        STAMP(1);
-        // per-subframe LDS state for the gather (the apply of the NEXT pass reads fcall / lcall)
-        for (int k = tid; k < nP; k += WG_THREADS) { L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0; }
-        if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
-        // header phase: lane l of the first wavefront waits for workgroup l's tag (relaxed sc1 polls, bounded),
-        // then reads its counts; exclusive prefix of the event counts by wave shuffles.
-        if (tid < 64) {
-            int nev = 0, nsuc = 0, ovf = 0, bad = 0;
-            if (tid < G) {
-                const long long *mb = reinterpret_cast<const long long *>(mb_of(C, parity, tid));
-                unsigned spins = 0;
-                unsigned long long h = (unsigned long long)ld_sc1_64(mb);
-                while ((int)(h & 0xffffu) != ((t + 1) & 0xffff)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > SPIN_LIMIT) { bad = 1; break; }
-                    h = (unsigned long long)ld_sc1_64(mb);
-                }
-                nev = (int)((h >> 16) & 0x1fffu); ovf = (int)((h >> 39) & 1u); nsuc = (int)(h >> 40);
+            for (int k = tid; k < nP; k += WG_THREADS) {
+                L.total[k] = L.hist[k]; L.fcall[k] = L.mloc[k];
+                L.hist[k] = 0; L.mloc[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0;
             }
-            int x = nev;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (tid >= d) x += y; }
-            L.evoff[tid] = x - nev;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { nsuc += __shfl_down(nsuc, d); ovf |= __shfl_down(ovf, d); bad |= __shfl_down(bad, d); }
-            if (tid == 63) L.scal[C_NTOT] = x;
-            if (tid == 0) { L.scal[C_NSUCCTOT] = nsuc; L.scal[C_OVF] = ovf; if (bad) L.scal[C_STATUS] = PRACH_ERR_INTERNAL; }
-        }
-        __syncthreads();
-        STAMP(2);
-        if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
-        const int N = L.scal[C_NTOT];
-        if (L.scal[C_OVF] || N > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
-
-        // payload phase: ONE round of sc1 loads — histograms / lowest callers of every workgroup, and every event
-        { // hist / mloc of every workgroup: 8-byte sc1 loads, all issued before the first LDS atomic
-            const int pairs = nP; // (4 + 2nP) ints per mailbox start 8-byte aligned: hist/mloc = nP pairs
-            for (int k0 = tid; k0 < G * pairs; k0 += 2 * WG_THREADS) {
-                const int k1 = k0 + WG_THREADS;
-                const int wg0 = k0 / pairs, q0 = k0 - wg0 * pairs;
-                const long long v0 = ld_sc1_64(reinterpret_cast<const long long *>(mb_of(C, parity, wg0) + 4) + q0);
-                long long v1 = 0;
-                int wg1 = 0, q1 = 0;
-                if (k1 < G * pairs) { wg1 = k1 / pairs; q1 = k1 - wg1 * pairs; v1 = ld_sc1_64(reinterpret_cast<const long long *>(mb_of(C, parity, wg1) + 4) + q1); }
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    if (h == 1 && k1 >= G * pairs) break;
-                    const long long v = h ? v1 : v0;
-                    const int q = h ? q1 : q0;
-#pragma unroll
-                    for (int z = 0; z < 2; z++) {
-                        const int kk = 2 * q + z, val = z ? (int)(v >> 32) : (int)(unsigned)v;
-                        if (kk < nP) { if (val) atomicAdd(&L.total[kk], val); }
-                        else if (val != INT_MAX) atomicMin(&L.fcall[kk - nP], val);
-                    }
+            __syncthreads();
+            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; L.scal[C_NSUCCTOT] = L.scal[C_NSUCC]; }
+            STAMP(1); STAMP(2);
+            if (nevraw > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
+            N = nevraw;
+            __syncthreads();
+        } else {
+            // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
+            {
+                const int nevraw = L.scal[C_NEV];
+                for (int k = tid; k < nP; k += WG_THREADS) {
+                    const int ml = L.mloc[k];
+                    st_sc1_64(mygr + 1 + k, mk_granule((unsigned)L.hist[k], ml == INT_MAX ? GR_NONE : (unsigned)ml, tag));
                 }
+                if (tid == 0)
+                    st_sc1_64(mygr, mk_granule((unsigned)min(nevraw, C.evw) | (nevraw > C.evw ? (1u << 13) : 0u), (unsigned)L.scal[C_NSUCC], tag));
             }
+            __syncthreads();
+            STAMP(1);
+            // per-subframe LDS state for the gather (the apply of the NEXT pass reads fcall / lcall)
+            for (int k = tid; k < nP; k += WG_THREADS) { L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0; }
+            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
+            __syncthreads();
+            // round 1: the bucket granules of every workgroup (all threads) and, on the last wavefront, the headers
+            for (int k = tid; k < G * nP; k += WG_THREADS) {
+                const int wg = k / nP, p = k - wg * nP;
+                const long long g_ = wait_granule(gr_of(C, parity, wg) + 1 + p, tag, &L.scal[C_STATUS]);
+                const unsigned h = (unsigned)g_ & 0xFFFFFu, ml = (unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu;
+                if (h) atomicAdd(&L.total[p], (int)h);
+                if (ml != GR_NONE) atomicMin(&L.fcall[p], (int)ml);
+            }
+            if (tid >= WG_THREADS - 64) {
+                const int l = tid - (WG_THREADS - 64);
+                int nev = 0, nsuc = 0, ovf = 0;
+                if (l < G) {
+                    const long long g_ = wait_granule(gr_of(C, parity, l), tag, &L.scal[C_STATUS]);
+                    const unsigned w0 = (unsigned)g_ & 0xFFFFFu;
+                    nev = (int)(w0 & 0x1FFFu); ovf = (int)((w0 >> 13) & 1u); nsuc = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu);
+                }
+                int x = nev;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (l >= d) x += y; }
+                L.evoff[l] = x - nev;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { nsuc += __shfl_down(nsuc, d); ovf |= __shfl_down(ovf, d); }
+                if (l == 63) L.scal[C_NTOT] = x;
+                if (l == 0) { L.scal[C_NSUCCTOT] = nsuc; L.scal[C_OVF] = ovf; }
+            }
+            __syncthreads();
+            STAMP(2);
+            if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
+            N = L.scal[C_NTOT];
+            if (L.scal[C_OVF] || N > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
+            // round 2: every event granule
+            for (int k = tid; k < N; k += WG_THREADS) {
+                int lo = 0, hi = G; // workgroup whose segment holds event k
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.evoff[mid] <= k) lo = mid; else hi = mid; }
+                const long long e = wait_granule(gr_of(C, parity, lo) + 1 + nP + (k - L.evoff[lo]), tag, &L.scal[C_STATUS]);
+                L.gev[k] = make_int2((int)((unsigned)e & 0xFFFFFu), (int)((unsigned)((unsigned long long)e >> 32) & 0xFFFFFu));
+            }
+            __syncthreads();
         }
-        for (int k = tid; k < N; k += WG_THREADS) {
-            int lo = 0, hi = G; // workgroup whose segment holds event k
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.evoff[mid] <= k) lo = mid; else hi = mid; }
-            const long long e = ld_sc1_64(reinterpret_cast<const long long *>(mb_of(C, parity, lo) + 4 + 2 * nP) + (k - L.evoff[lo]));
-            L.gev[k] = make_int2((int)(unsigned)e, (int)(e >> 32));
-        }
-        __syncthreads();
         // classify the gathered events (fcall now holds the lowest DEFINITE caller of every bucket)
         for (int k = tid; k < N; k += WG_THREADS) {
             const int2 ev = L.gev[k];
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             if (type == EVC_RESETCAND) {
                 // a call on its old bucket by a definite caller with a lower index bumps it: cannot re-join
                 // (99.7 % of them; only the survivors need the index-ordered treatment)
-                if (L.fcall[(ev.y >> 16) & 0xff] < ev.x) L.gev[k].y = 0;
+                if (L.fcall[(ev.y >> 12) & 0xff] < ev.x) L.gev[k].y = 0;
                 else { const int s = atomicAdd(&L.scal[C_NRC], 1); if (s < RCCAP) L.rclist[s] = k; }
             } else if (type == EVC_RJOIN) atomicAdd(&L.scal[C_NRJ], 1);
         }
@@ -529,7 +552,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         STAMP(4);
         for (int k = tid; k < N; k += WG_THREADS) {
             const int2 e = L.gev[k];
-            const int type = e.y & 7, p = (e.y >> 8) & 0xff;
+            const int type = e.y & 7, p = (e.y >> 4) & 0xff;
             if (type == EVC_LEAVER) { if (e.x < L.fcall[p]) atomicAdd(&L.nlv[p], 1); }
             else if ((type == EVC_CALLER || type == EVC_RESETCAND) && e.x == L.fcall[p]) L.fie[p] = 1;
         }
@@ -546,7 +569,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             if (k < N) {
                 const int2 e = L.gev[k];
                 const int type = e.y & 7;
-                if (type == EVC_CALLER || type == EVC_RESETCAND) { caller = true; idx = e.x; p = (e.y >> 8) & 0xff; ispre = (e.y >> 3) & 1; }
+                if (type == EVC_CALLER || type == EVC_RESETCAND) { caller = true; idx = e.x; p = (e.y >> 4) & 0xff; ispre = (e.y >> 3) & 1; }
             } else {
                 p = k - N;
                 if (L.fcall[p] != INT_MAX && !L.fie[p]) { caller = true; idx = L.fcall[p]; ispre = 1; } // a STAY pre-member calls first
@@ -559,11 +582,11 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 for (int j = 0; j < N; j++) {
                     const int2 ej = L.gev[j];
                     const int tj = ej.y & 7;
-                    if ((tj == EVC_CALLER || tj == EVC_RESETCAND) && ((ej.y >> 8) & 0xff) == p && ej.x < idx && ej.x > prev) prev = ej.x;
+                    if ((tj == EVC_CALLER || tj == EVC_RESETCAND) && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) prev = ej.x;
                 }
                 for (int j = 0; j < N; j++) {
                     const int2 ej = L.gev[j];
-                    if ((ej.y & 7) == EVC_RJOIN && ((ej.y >> 8) & 0xff) == p && ej.x < idx && ej.x > prev) rj++;
+                    if ((ej.y & 7) == EVC_RJOIN && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) rj++;
                 }
             }
             const int check = 1 + (first ? L.total[p] - ispre - L.nlv[p] : 0) + rj;
@@ -641,7 +664,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }
     __syncthreads();
-    if (status == PRACH_OK && tlast >= 0) cluster_pass<true>(P, L, C, FM, tlast + 1, activeCheck, activeCheck, nullptr);
+    if (status == PRACH_OK && tlast >= 0) cluster_pass<true>(P, L, C, FM, tlast + 1, activeCheck, activeCheck, nullptr, 0u);
     __syncthreads();
 
     // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of the owned UEs

@@ -68,7 +68,7 @@ TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t
     L.evw = 0; L.mbstride = 0; L.mbox = L.bar = L.cand = 0;
     if (G > 0) { // cluster kernel: mailboxes, arrival counter, early-leaver candidate scratch
         L.evw = G == 1 ? 4096 : 512;
-        L.mbstride = (int)align_up((size_t)(4 + 2 * c.nPreamble + 2 * L.evw), 4);
+        L.mbstride = (int)align_up((size_t)2 * (1 + c.nPreamble + L.evw), 4); // 8-byte granules: header, buckets, events
         L.mbox = take(4 * (size_t)2 * G * L.mbstride);
         L.bar = take(256);
         L.cand = take(8 * (n + 64 * (size_t)G + 64));
@@ -323,7 +323,7 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
             if (cfgs[k].rng_mode == mode && cfgs[k].variant != PRACH_VARIANT_NOMA_C) idx.push_back(k);
         if (idx.empty()) continue;
         bool cluster_ok = mode == PRACH_RNG_PHILOX && !e->opt_legacy;
-        for (int k : idx) cluster_ok = cluster_ok && cfgs[k].nUE <= (1 << 20); // dead-group bitmap / header granule limits
+        for (int k : idx) cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
         if (cluster_ok) {
             // production path: cluster kernel, G workgroups per trial (all clusters must be co-resident:
             // at most one 1024-thread workgroup per CU is assumed, 256 CUs)
