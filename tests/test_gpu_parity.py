@@ -181,3 +181,73 @@ def test_cli_drop_in_files(pkg, engine, tmp_path):
         d = tmp_path / tr["dir"]
         assert (d / tr["results_file"]).read_text() == tr["results_text"]
         assert hashlib.sha256((d / tr["logs_file"]).read_bytes()).hexdigest() == tr["logs_sha256"]
+
+
+@pytest.mark.parametrize("G", [1, 2, 4, 16, 64])
+def test_cluster_sizes_agree(pkg, ob, engine, G):
+    """The Philox production kernel with G workgroups per trial (interleaved ownership + granule exchange)
+    gives the same trial for every cluster size, = the oracle."""
+    engine.set("cluster", G)
+    try:
+        for variant, n in ((0, 20000), (1, 20000)):
+            cfg = pkg.make_cfg(n, variant=variant, rng_mode=pkg.RNG_PHILOX, seed=17)
+            (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+            assert engine.timing().workgroups == G
+            ores, oues = ob.run_trial(ob.make_cfg(n, variant=variant), ob.Rng(ob.RNG_PHILOX, 17))
+            assert_same(pkg, res, logs, ores, oues, (G, variant))
+    finally:
+        engine.set("cluster", 0)
+
+
+def test_several_clusters_in_one_launch(pkg, ob, engine):
+    """4 trials x 16 workgroups in one launch (cluster id = blockIdx %% trials), mixed variants and sizes."""
+    engine.set("cluster", 16)
+    try:
+        cfgs = [pkg.make_cfg(n, variant=v, rng_mode=pkg.RNG_PHILOX, seed=s) for (n, v, s) in
+                [(25000, 0, 1), (18000, 1, 2), (30000, 1, 3), (16000, 0, 4)]]
+        res, logs = engine.run_trials(cfgs, want_logs=True)
+        assert engine.timing().workgroups == 64 and engine.timing().launches == 1
+        for c, r, l in zip(cfgs, res, logs):
+            ores, oues = ob.run_trial(ob.make_cfg(c.nUE, variant=c.variant), ob.Rng(ob.RNG_PHILOX, int(c.seed)))
+            assert_same(pkg, r, l, ores, oues, (c.nUE, c.variant))
+    finally:
+        engine.set("cluster", 0)
+
+
+def test_cluster_capacity_fallback_is_exact(pkg, ob, engine):
+    """backoff 1 makes every retransmission land on the same subframe: thousands of special events per subframe
+    exceed the cluster kernel's per-subframe LDS capacities; the engine reruns such trials on the
+    one-workgroup kernel (global scratch, no caps) — still bit-exact."""
+    kw = dict(nPreamble=3, backoff=1, nGrantUL=12, maxRarWindow=2, maxMsg2TxCount=3)
+    cfg = pkg.make_cfg(60000, variant=1, rng_mode=pkg.RNG_PHILOX, seed=2, **kw)
+    (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+    assert engine.timing().launches == 2  # cluster attempt + exact rerun
+    ores, oues = ob.run_trial(ob.make_cfg(60000, variant=1, **kw), ob.Rng(ob.RNG_PHILOX, 2))
+    assert_same(pkg, res, logs, ores, oues, "fallback")
+
+
+def test_legacy_kernel_option(pkg, ob, engine):
+    engine.set("legacy", 1)
+    try:
+        cfg = pkg.make_cfg(9000, variant=1, rng_mode=pkg.RNG_PHILOX, seed=8)
+        (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+    finally:
+        engine.set("legacy", 0)
+    ores, oues = ob.run_trial(ob.make_cfg(9000, variant=1), ob.Rng(ob.RNG_PHILOX, 8))
+    assert_same(pkg, res, logs, ores, oues, "legacy")
+
+
+def test_cli_noma_program(pkg, ob, engine, tmp_path):
+    """prach_sim --program noma: NOMA.c's output surface (one line per (seed, nUE), appended per-nUE files, Done)."""
+    p = subprocess.run([pkg.CLI_PATH, "--program", "noma", "--times", "2", "--sweep", "3000:6000:3000", "--out", str(tmp_path)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    exp = []
+    for seed in range(2):
+        for n in (3000, 6000):
+            ocfg = ob.make_noma_cfg(n)
+            ores, _ = ob.noma_run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, seed), want_ues=False)
+            exp.append(ob.noma_format_line(ocfg, ores).decode())
+        exp.append("Done\n")
+    assert p.stdout == "".join(exp)
+    assert (tmp_path / "TestResults" / "Sector_3000_Result.txt").read_text() == exp[0] + exp[3]
