@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of reference-CPU timing (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL over xGMI; gloo only to rehearse on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -96,12 +98,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    if args.same_device:
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collective's tensors live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     eng = pkg.Engine(local_rank)
     # the workload: RandomAccessSimulatorBeta.c as committed (Beta.c:47-57), one trial per GPU
@@ -132,9 +140,9 @@ def main():
     tot_updates, max_dt = updates, dt
     if dist is not None:
         # the one collective of the job: final aggregates (success counts, updates) summed over ranks (RCCL)
-        t = torch.tensor([updates, agg_succ], dtype=torch.int64, device=dev)
+        t = torch.tensor([updates, agg_succ], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        tm = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         tot_updates, agg_succ, max_dt = int(t[0]), int(t[1]), float(tm[0])
 
