@@ -172,8 +172,44 @@ int main(int argc, char *argv[]) {
     if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
 
     const int npts = (sweep_hi - sweep_lo) / sweep_step + 1;
-    prach_ue_log *logbuf = want_logs ? (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)sweep_hi) : NULL;
     char text[4096];
+    if (rng == PRACH_RNG_PHILOX) {
+        /* Philox trials are independent: the whole --times x sweep grid runs concurrently in ONE call
+         * (one workgroup cluster per trial); output order and files are the reference's. */
+        const int ntr = randomMax * npts;
+        prach_cfg *cfgs = (prach_cfg *)malloc(sizeof(prach_cfg) * (size_t)ntr);
+        prach_result *res = (prach_result *)malloc(sizeof(prach_result) * (size_t)ntr);
+        prach_ue_log **logs = want_logs ? (prach_ue_log **)calloc((size_t)ntr, sizeof(prach_ue_log *)) : NULL;
+        if (!cfgs || !res || (want_logs && !logs)) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+        for (int s_ = 0; s_ < randomMax; s_++)
+            for (int k = 0; k < npts; k++) {
+                prach_cfg *c = &cfgs[s_ * npts + k];
+                *c = base;
+                c->nUE = sweep_lo + k * sweep_step;
+                c->seed = (uint64_t)s_;
+                if (want_logs) {
+                    logs[s_ * npts + k] = (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)c->nUE);
+                    if (!logs[s_ * npts + k]) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+                }
+            }
+        struct timespec ts0, ts1;
+        clock_gettime(CLOCK_MONOTONIC, &ts0);
+        rc = prach_run_trials(eng, cfgs, ntr, res, logs);
+        if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+        clock_gettime(CLOCK_MONOTONIC, &ts1);
+        const double lat = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
+        for (int k = 0; k < ntr; k++) {
+            prach_format_stdout(&cfgs[k], &res[k], lat, text, sizeof text);
+            fputs(text, stdout);
+            rc = prach_write_trial_files(&cfgs[k], &res[k], want_logs ? logs[k] : NULL, lat, outdir);
+            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+            if (want_logs) free(logs[k]);
+        }
+        free(cfgs); free(res); free(logs);
+        prach_engine_destroy(eng);
+        return 0;
+    }
+    prach_ue_log *logbuf = want_logs ? (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)sweep_hi) : NULL;
     for (int randomSeed = 0; randomSeed < randomMax; randomSeed++) { /* WithNOMA:216 */
         struct timespec ts0, ts1;
         clock_gettime(CLOCK_MONOTONIC, &ts0);

@@ -76,8 +76,8 @@ __device__ __forceinline__ CLds ccarve(char *smem, int nP) {
     L.evoff = ip; ip += MAXG + 16;
     L.bins = ip; ip += GBINS;
     L.wtot = ip; ip += NW;
-    L.hist = ip; ip += nP; L.mloc = ip; ip += nP; L.total = ip; ip += nP; L.fcall = ip; ip += nP;
-    L.lcall = ip; ip += nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
+    L.hist = ip; ip += nP; L.mloc = ip; ip += nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
+    L.lcall = ip; ip += 2 * nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
     return L;
 }
 
@@ -129,7 +129,8 @@ __device__ __forceinline__ long long *gr_of(const Ctx &C, int parity, int wg) {
 // pass over the groups this workgroup owns.  FINAL: only the deferred apply of the last subframe.
 // ---------------------------------------------------------------------------------------------
 template <bool FINAL>
-__device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, const Ctx &C, const FastMods &FM, const int t, const int prevAC,
+__device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall, const int *lcall,
+                                             const int t, const int prevAC,
                                              const int activeCheck, long long *mbev, const unsigned tag) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int aT = P.aT, nUE = P.nUE;
@@ -182,14 +183,14 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
                 u.tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
             } else if (u.pend == PEND_RESET) {
                 const int q = u.bo, tmp = u.tx;
-                const int bumped = L.fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
+                const int bumped = fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
                 const int x = slot_align_fm(tp + bumped + tmp, fmA);
                 if (x == tp) { u.bo = 0; u.tx = tp + 1; }
                 else { u.tx = x; u.bo = x; }
             } else if (u.pend == PEND_PASSIVE) {
-                if (L.fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
+                if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
             } else { // PEND_RJOIN
-                if (L.lcall[u.pre - 1] > i) u.tx = tp + 1;
+                if (lcall[u.pre - 1] > i) u.tx = tp + 1;
             }
             u.pend = PEND_NONE;
             dirty = true;
@@ -335,6 +336,23 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
     }
 }
 
+// One gathered event against the lowest DEFINITE caller of every bucket (complete after round 1).
+__device__ __forceinline__ void classify_event(const CLds &L, int *fcallA, const int k, const int2 ev) {
+    const int type = ev.y & 7, p = (ev.y >> 4) & 0xff;
+    if (type == EVC_RESETCAND) {
+        // a call on its old bucket by a definite caller with a lower index bumps it: cannot re-join (99.7 % of
+        // them); only the survivors need the index-ordered treatment
+        if (fcallA[(ev.y >> 12) & 0xff] < ev.x) L.gev[k].y = 0;
+        else { const int s = atomicAdd(&L.scal[C_NRC], 1); if (s < RCCAP) L.rclist[s] = k; }
+    } else if (type == EVC_RJOIN) {
+        atomicAdd(&L.scal[C_NRJ], 1);
+    } else if (type == EVC_LEAVER) {
+        if (ev.x < fcallA[p]) atomicAdd(&L.nlv[p], 1);
+    } else if (type == EVC_CALLER) {
+        if (ev.x == fcallA[p]) L.fie[p] = 1;
+    }
+}
+
 // Reset-cycle candidates (Beta.c:250-281 with tmp == 0 on a subframe = 1 mod accessTime): candidate i
 // re-joins (and calls on its NEW preamble) iff nobody called on its OLD preamble before it, and a
 // re-join is itself a call that later candidates must see.  Inherently sequential in index order,
@@ -349,11 +367,11 @@ __device__ __forceinline__ int fc_get(int f0, int f1, int f2, int f3, int q) {
     default: return __builtin_amdgcn_readlane(f3, l);
     }
 }
-__device__ __forceinline__ void resolve_reset_candidates(const CLds &L, const int nrc_in, const int nP) {
+__device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fcall, const int nrc_in, const int nP) {
     const int lane = threadIdx.x & 63;
     const int n = __builtin_amdgcn_readfirstlane(nrc_in);
-    int f0 = lane < nP ? L.fcall[lane] : INT_MAX, f1 = lane + 64 < nP ? L.fcall[lane + 64] : INT_MAX,
-        f2 = lane + 128 < nP ? L.fcall[lane + 128] : INT_MAX, f3 = lane + 192 < nP ? L.fcall[lane + 192] : INT_MAX;
+    int f0 = lane < nP ? fcall[lane] : INT_MAX, f1 = lane + 64 < nP ? fcall[lane + 64] : INT_MAX,
+        f2 = lane + 128 < nP ? fcall[lane + 128] : INT_MAX, f3 = lane + 192 < nP ? fcall[lane + 192] : INT_MAX;
     // rank-sort the candidate list by UE index into L.sidx (free at this point of the subframe)
     for (int c = lane; c < n; c += 64) {
         const int myidx = L.gev[L.rclist[c]].x;
@@ -382,10 +400,10 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, const in
         }
         if (lane < m && cancelled) L.gev[slot].y = 0;
     }
-    if (lane < nP) L.fcall[lane] = f0;
-    if (lane + 64 < nP) L.fcall[lane + 64] = f1;
-    if (lane + 128 < nP) L.fcall[lane + 128] = f2;
-    if (lane + 192 < nP) L.fcall[lane + 192] = f3;
+    if (lane < nP) fcall[lane] = f0;
+    if (lane + 64 < nP) fcall[lane + 64] = f1;
+    if (lane + 128 < nP) fcall[lane + 128] = f2;
+    if (lane + 192 < nP) fcall[lane + 192] = f3;
 }
 
 } // namespace
@@ -417,7 +435,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         }
     }
     for (int k = tid; k < nP; k += WG_THREADS) {
-        L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0;
+        L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.fcall[nP + k] = INT_MAX; L.lcall[nP + k] = -1;
+        L.nlv[k] = 0; L.fie[k] = 0;
     }
     if (tid < 64) L.scal[tid] = 0;
     for (int k = tid; k < DEADW; k += WG_THREADS) L.dead[k] = 0;
@@ -441,9 +460,13 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         const unsigned tag = (unsigned)(t + 1);
         long long *const mygr = G > 1 ? gr_of(C, parity, b) : nullptr;
         long long *const mbev = G > 1 ? mygr + 1 + nP : nullptr;
+        // first / last caller tables are double-buffered by subframe parity: this subframe's resolver fills [A],
+        // the pass (apply of the previous subframe) reads [B]
+        int *const fcallA = L.fcall + parity * nP, *const lcallA = L.lcall + parity * nP;
+        int *const fcallB = L.fcall + (parity ^ 1) * nP, *const lcallB = L.lcall + (parity ^ 1) * nP;
 
-        cluster_pass<false>(P, L, C, FM, t, prevAC, activeCheck, mbev, tag);
-        __syncthreads();
+        cluster_pass<false>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag);
+        __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
         STAMP(0);
 
         // early leavers below this workgroup's lowest caller are the only ones a rank can need
@@ -457,45 +480,44 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)c.x, (unsigned)info, tag));
             }
         }
-        __syncthreads();
+        for (int k = tid; k < nP; k += WG_THREADS) { fcallB[k] = INT_MAX; lcallB[k] = -1; } // ready for subframe t+1
+        __syncthreads(); // S2
         int N;
         if (G == 1) {
             // one workgroup owns the whole trial: its histogram / lowest callers ARE the totals; events are in LDS
             const int nevraw = L.scal[C_NEV];
             for (int k = tid; k < nP; k += WG_THREADS) {
-                L.total[k] = L.hist[k]; L.fcall[k] = L.mloc[k];
-                L.hist[k] = 0; L.mloc[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0;
+                L.total[k] = L.hist[k]; fcallA[k] = L.mloc[k];
+                L.hist[k] = 0; L.mloc[k] = INT_MAX;
             }
-            __syncthreads();
-            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; L.scal[C_NSUCCTOT] = L.scal[C_NSUCC]; }
-            STAMP(1); STAMP(2);
             if (nevraw > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
             N = nevraw;
-            __syncthreads();
+            __syncthreads(); // S3
+            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NSUCCTOT] = L.scal[C_NSUCC]; }
+            STAMP(1); STAMP(2);
+            // classify the events: reset-cycle candidates, Msg3 re-entries, early leavers below / callers at the first call
+            for (int k = tid; k < N; k += WG_THREADS) classify_event(L, fcallA, k, L.gev[k]);
         } else {
-            // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
-            {
-                const int nevraw = L.scal[C_NEV];
-                for (int k = tid; k < nP; k += WG_THREADS) {
-                    const int ml = L.mloc[k];
-                    st_sc1_64(mygr + 1 + k, mk_granule((unsigned)L.hist[k], ml == INT_MAX ? GR_NONE : (unsigned)ml, tag));
-                }
-                if (tid == 0)
-                    st_sc1_64(mygr, mk_granule((unsigned)min(nevraw, C.evw) | (nevraw > C.evw ? (1u << 13) : 0u), (unsigned)L.scal[C_NSUCC], tag));
+            // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating
+            // granules; the publishing thread also clears its histogram slot for the next pass
+            for (int k = tid; k < nP; k += WG_THREADS) {
+                const int ml = L.mloc[k];
+                st_sc1_64(mygr + 1 + k, mk_granule((unsigned)L.hist[k], ml == INT_MAX ? GR_NONE : (unsigned)ml, tag));
+                L.hist[k] = 0; L.mloc[k] = INT_MAX;
             }
-            __syncthreads();
+            if (tid == 0) {
+                const int nevraw = L.scal[C_NEV];
+                st_sc1_64(mygr, mk_granule((unsigned)min(nevraw, C.evw) | (nevraw > C.evw ? (1u << 13) : 0u), (unsigned)L.scal[C_NSUCC], tag));
+                L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0;
+            }
             STAMP(1);
-            // per-subframe LDS state for the gather (the apply of the NEXT pass reads fcall / lcall)
-            for (int k = tid; k < nP; k += WG_THREADS) { L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.nlv[k] = 0; L.fie[k] = 0; }
-            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
-            __syncthreads();
             // round 1: the bucket granules of every workgroup (all threads) and, on the last wavefront, the headers
             for (int k = tid; k < G * nP; k += WG_THREADS) {
                 const int wg = k / nP, p = k - wg * nP;
                 const long long g_ = wait_granule(gr_of(C, parity, wg) + 1 + p, tag, &L.scal[C_STATUS]);
                 const unsigned h = (unsigned)g_ & 0xFFFFFu, ml = (unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu;
                 if (h) atomicAdd(&L.total[p], (int)h);
-                if (ml != GR_NONE) atomicMin(&L.fcall[p], (int)ml);
+                if (ml != GR_NONE) atomicMin(&fcallA[p], (int)ml);
             }
             if (tid >= WG_THREADS - 64) {
                 const int l = tid - (WG_THREADS - 64);
@@ -514,53 +536,44 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 if (l == 63) L.scal[C_NTOT] = x;
                 if (l == 0) { L.scal[C_NSUCCTOT] = nsuc; L.scal[C_OVF] = ovf; }
             }
-            __syncthreads();
+            __syncthreads(); // S3: totals, lowest definite callers, event offsets
             STAMP(2);
             if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
             N = L.scal[C_NTOT];
             if (L.scal[C_OVF] || N > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
-            // round 2: every event granule
+            // round 2: every event granule, classified on arrival
             for (int k = tid; k < N; k += WG_THREADS) {
                 int lo = 0, hi = G; // workgroup whose segment holds event k
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.evoff[mid] <= k) lo = mid; else hi = mid; }
                 const long long e = wait_granule(gr_of(C, parity, lo) + 1 + nP + (k - L.evoff[lo]), tag, &L.scal[C_STATUS]);
-                L.gev[k] = make_int2((int)((unsigned)e & 0xFFFFFu), (int)((unsigned)((unsigned long long)e >> 32) & 0xFFFFFu));
+                const int2 ev = make_int2((int)((unsigned)e & 0xFFFFFu), (int)((unsigned)((unsigned long long)e >> 32) & 0xFFFFFu));
+                L.gev[k] = ev;
+                classify_event(L, fcallA, k, ev);
             }
-            __syncthreads();
         }
-        // classify the gathered events (fcall now holds the lowest DEFINITE caller of every bucket)
-        for (int k = tid; k < N; k += WG_THREADS) {
-            const int2 ev = L.gev[k];
-            const int type = ev.y & 7;
-            if (type == EVC_RESETCAND) {
-                // a call on its old bucket by a definite caller with a lower index bumps it: cannot re-join
-                // (99.7 % of them; only the survivors need the index-ordered treatment)
-                if (L.fcall[(ev.y >> 12) & 0xff] < ev.x) L.gev[k].y = 0;
-                else { const int s = atomicAdd(&L.scal[C_NRC], 1); if (s < RCCAP) L.rclist[s] = k; }
-            } else if (type == EVC_RJOIN) atomicAdd(&L.scal[C_NRJ], 1);
-        }
-        __syncthreads();
+        __syncthreads(); // S4: events gathered and classified against the lowest DEFINITE callers
         STAMP(3);
 
         // ---- resolve (identical on every workgroup of the cluster) ----
         const int nrc = L.scal[C_NRC];
-        if (nrc > 0) { // reset cycles that could land on this subframe: decided strictly in index order
+        if (nrc > 0) { // rare: reset cycles that may re-join — decided strictly in index order, then recount
             if (nrc > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
-            if (tid < 64) resolve_reset_candidates(L, nrc, nP);
+            if (tid < 64) resolve_reset_candidates(L, fcallA, nrc, nP);
+            for (int k = 64 + tid; k < 64 + nP; k += WG_THREADS) { L.nlv[k - 64] = 0; L.fie[k - 64] = 0; }
+            __syncthreads();
+            for (int k = tid; k < N; k += WG_THREADS) {
+                const int2 e = L.gev[k];
+                const int type = e.y & 7, p = (e.y >> 4) & 0xff;
+                if (type == EVC_LEAVER) { if (e.x < fcallA[p]) atomicAdd(&L.nlv[p], 1); }
+                else if ((type == EVC_CALLER || type == EVC_RESETCAND) && e.x == fcallA[p]) L.fie[p] = 1;
+            }
             __syncthreads();
         }
-        STAMP(4);
-        for (int k = tid; k < N; k += WG_THREADS) {
-            const int2 e = L.gev[k];
-            const int type = e.y & 7, p = (e.y >> 4) & 0xff;
-            if (type == EVC_LEAVER) { if (e.x < L.fcall[p]) atomicAdd(&L.nlv[p], 1); }
-            else if ((type == EVC_CALLER || type == EVC_RESETCAND) && e.x == L.fcall[p]) L.fie[p] = 1;
-        }
-        __syncthreads();
-        STAMP(5);
+        STAMP(4); STAMP(5);
 #ifdef PRACH_STAMPS
         if (tid == 0) { statN += (unsigned long long)N; if ((unsigned long long)N > maxN) maxN = N; statRC += (unsigned long long)nrc; }
 #endif
+        // every call: scan count `check` (Beta.c:321-330), counters (Beta.c:334,349-351 / WithNOMA:650-652)
         const int nrj = L.scal[C_NRJ];
         int my_coll = 0, my_txop = 0;
         for (int k = tid; k < N + nP; k += WG_THREADS) {
@@ -572,13 +585,13 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 if (type == EVC_CALLER || type == EVC_RESETCAND) { caller = true; idx = e.x; p = (e.y >> 4) & 0xff; ispre = (e.y >> 3) & 1; }
             } else {
                 p = k - N;
-                if (L.fcall[p] != INT_MAX && !L.fie[p]) { caller = true; idx = L.fcall[p]; ispre = 1; } // a STAY pre-member calls first
+                if (fcallA[p] != INT_MAX && !L.fie[p]) { caller = true; idx = fcallA[p]; ispre = 1; } // a STAY pre-member calls first
             }
             if (!caller) continue;
-            const bool first = idx == L.fcall[p];
+            const bool first = idx == fcallA[p];
             int rj = 0;
             if (nrj > 0) { // Msg3-timeout re-entries that stayed matched since the previous call on this bucket (rare)
-                int prev = (!first) ? L.fcall[p] : -1;
+                int prev = (!first) ? fcallA[p] : -1;
                 for (int j = 0; j < N; j++) {
                     const int2 ej = L.gev[j];
                     const int tj = ej.y & 7;
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 }
             }
             const int check = 1 + (first ? L.total[p] - ispre - L.nlv[p] : 0) + rj;
-            if (L.lcall[p] < idx) atomicMax(&L.lcall[p], idx);
+            if (lcallA[p] < idx) atomicMax(&lcallA[p], idx);
             if (check == 1) {
                 const int s = atomicAdd(&L.scal[C_NS], 1);
                 if (s < SCAPC) L.sidx[s] = idx;
@@ -604,10 +617,11 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { my_coll += __shfl_down(my_coll, d); my_txop += __shfl_down(my_txop, d); }
         if ((tid & 63) == 0) { if (my_coll) atomicAdd(&L.scal[C_COLL], my_coll); if (my_txop) atomicAdd(&L.scal[C_TXOP], my_txop); }
-        __syncthreads();
+        __syncthreads(); // S5: calls done; singles listed
         STAMP(6);
         const int ns = L.scal[C_NS];
         if (ns > SCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+        for (int k = tid; k < nP; k += WG_THREADS) { L.total[k] = 0; L.nlv[k] = 0; L.fie[k] = 0; } // free now; ready for subframe t+1
         const int Gr = max(0, P.nGrantUL - 1 - grantCheck); // Beta.c:336-347
         if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
             // the Gr lowest-index singleton callers, in O(ns): counts per index bin (1024 bins over [0,nUE)),
@@ -615,6 +629,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             // ranked exactly.  The grant itself is ONE atomicOr into the UE's record by the UE's owner.
             const int binshift = P.binshift;
             L.bins[tid] = 0;
+            if (tid == 0) L.scal[C_NCROSS] = 0;
             __syncthreads();
             for (int j = tid; j < ns; j += WG_THREADS) atomicAdd(&L.bins[L.sidx[j] >> binshift], 1);
             __syncthreads();
@@ -632,8 +647,6 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             __syncthreads();
             // whole bins below the crossing bin: granted; members of the (single) crossing bin: compacted, then
             // ranked among themselves
-            if (tid == 0) L.scal[C_NCROSS] = 0;
-            __syncthreads();
             for (int j = tid; j < ns; j += WG_THREADS) {
                 const int my = L.sidx[j];
                 const int bin = my >> binshift;
@@ -655,7 +668,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         }
         grantCheck += ns;
         const int nsucc_tot = L.scal[C_NSUCCTOT];
-        __syncthreads();
+        __syncthreads(); // S6: grants are in the records; per-subframe LDS state is clean
+        if (tid == 0) { L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
         STAMP(7);
 #ifdef PRACH_STAMPS
         if (tid == 0) { statNS += (unsigned long long)ns; if ((unsigned long long)ns > maxNS) maxNS = ns; }
@@ -664,7 +678,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }
     __syncthreads();
-    if (status == PRACH_OK && tlast >= 0) cluster_pass<true>(P, L, C, FM, tlast + 1, activeCheck, activeCheck, nullptr, 0u);
+    if (status == PRACH_OK && tlast >= 0) cluster_pass<true>(P, L, C, FM, L.fcall + (tlast & 1) * nP, L.lcall + (tlast & 1) * nP, tlast + 1, activeCheck, activeCheck, nullptr, 0u);
     __syncthreads();
 
     // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of the owned UEs
@@ -727,7 +741,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 }
 
 size_t cluster_kernel_lds_bytes(int nP) {
-    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 7 * nP);
+    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 9 * nP);
 }
 
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream) {

@@ -251,3 +251,22 @@ def test_cli_noma_program(pkg, ob, engine, tmp_path):
         exp.append("Done\n")
     assert p.stdout == "".join(exp)
     assert (tmp_path / "TestResults" / "Sector_3000_Result.txt").read_text() == exp[0] + exp[3]
+
+
+def test_cli_philox_grid_in_one_call(pkg, ob, engine, tmp_path):
+    """--rng philox: the --times x sweep grid is one batched call; stdout order and files follow the reference."""
+    p = subprocess.run([pkg.CLI_PATH, "--rng", "philox", "--times", "2", "--sweep", "4000:8000:4000", "--out", str(tmp_path), "--logs", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    blocks = split_stdout_blocks(p.stdout)
+    assert len(blocks) == 4
+    k = 0
+    for seed in range(2):
+        for n in (4000, 8000):
+            ocfg = ob.make_cfg(n, variant=1)
+            ores, oues = ob.run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, seed))
+            assert blocks[k] == ob.format_stdout(ocfg, ores).decode()
+            d = tmp_path / "NomaBetaResults"
+            assert (d / f"{seed}_54_{n}_Results.txt").read_bytes() == ob.format_results(ocfg, ores)
+            assert (d / f"{seed}_54_UE{n:05d}_Logs.txt").read_bytes() == ob.format_logs(oues, n)
+            k += 1
