@@ -480,7 +480,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)c.x, (unsigned)info, tag));
             }
         }
-        for (int k = tid; k < nP; k += WG_THREADS) { fcallB[k] = INT_MAX; lcallB[k] = -1; } // ready for subframe t+1
+        for (int k = tid; k < nP; k += WG_THREADS) { fcallB[k] = INT_MAX; lcallB[k] = -1; L.total[k] = 0; L.nlv[k] = 0; L.fie[k] = 0; } // ready for the gathers
+        if (tid == 0) { L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
         __syncthreads(); // S2
         int N;
         if (G == 1) {
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 classify_event(L, fcallA, k, ev);
             }
         }
-        __syncthreads(); // S4: events gathered and classified against the lowest DEFINITE callers
+        if (N > 0) __syncthreads(); // S4: events gathered and classified against the lowest DEFINITE callers (N is uniform)
         STAMP(3);
 
         // ---- resolve (identical on every workgroup of the cluster) ----
@@ -621,7 +622,6 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         STAMP(6);
         const int ns = L.scal[C_NS];
         if (ns > SCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
-        for (int k = tid; k < nP; k += WG_THREADS) { L.total[k] = 0; L.nlv[k] = 0; L.fie[k] = 0; } // free now; ready for subframe t+1
         const int Gr = max(0, P.nGrantUL - 1 - grantCheck); // Beta.c:336-347
         if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
             // the Gr lowest-index singleton callers, in O(ns): counts per index bin (1024 bins over [0,nUE)),
@@ -668,8 +668,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         }
         grantCheck += ns;
         const int nsucc_tot = L.scal[C_NSUCCTOT];
-        __syncthreads(); // S6: grants are in the records; per-subframe LDS state is clean
-        if (tid == 0) { L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
+        if (Gr > 0 && ns > 0) __syncthreads(); // S6: the grants are in the records before the next pass reads them
         STAMP(7);
 #ifdef PRACH_STAMPS
         if (tid == 0) { statNS += (unsigned long long)ns; if ((unsigned long long)ns > maxNS) maxNS = ns; }
