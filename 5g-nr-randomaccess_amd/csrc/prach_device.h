@@ -85,6 +85,6 @@ size_t cluster_kernel_lds_bytes(int nP);
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
 constexpr int CLUSTER_MAX_G = 64;
 size_t noma_kernel_lds_bytes(int nP);
-hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int maxP, hipStream_t stream);
+hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
 
 } // namespace prach

@@ -69,6 +69,7 @@ TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t
     if (G > 0) { // cluster kernel: mailboxes, arrival counter, early-leaver candidate scratch
         L.evw = G == 1 ? 4096 : 512;
         L.mbstride = (int)align_up((size_t)2 * (1 + c.nPreamble + L.evw), 4); // 8-byte granules: header, buckets, events
+        if (c.variant == PRACH_VARIANT_NOMA_C) L.mbstride = (int)align_up((size_t)2 * (1 + 6 * c.nPreamble), 4); // header + 6 x nP bins
         L.mbox = take(4 * (size_t)2 * G * L.mbstride);
         L.bar = take(256);
         L.cand = take(8 * (n + 64 * (size_t)G + 64));
@@ -236,7 +237,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     upload_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
 
     HIPCHK(hipEventRecord(e->ev0, e->stream));
-    if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, maxP, e->stream));
+    if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
     else if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
@@ -272,6 +273,10 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         r.sumTimer = dr.sumTimer;
         r.draws = dr.draws;
         r.steps = dr.steps;
+        if (c.variant == PRACH_VARIANT_NOMA_C && dr.nSuccess == c.nUE && dr.dbg[0] > 0) { // all UEs succeeded: NOMA.c:707-710 breaks there
+            r.time_exit = (int32_t)dr.dbg[0] - 1;
+            r.steps = dr.dbg[0];
+        }
         if (std::getenv("PRACH_PRINT_STAMPS"))
             std::fprintf(stderr, "[prach stamps/step] pass=%.0f publish=%.0f barrier=%.0f gather=%.0f r1b=%.0f leavers=%.0f checks=%.0f grants=%.0f cycles | N avg %.1f max %llu, resetcand avg %.2f, singles avg %.1f max %llu\n",
                          dr.stamps6[0] / (double)dr.steps, dr.stamps6[1] / (double)dr.steps, dr.stamps6[2] / (double)dr.steps, dr.stamps6[3] / (double)dr.steps,
@@ -308,12 +313,19 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
     auto t0 = std::chrono::steady_clock::now();
     e->last = prach_timing{};
     double kernel_ms = 0, upload_ms = 0;
-    { // NOMA.c variant: its own kernel
+    { // NOMA.c variant: its own kernel, G workgroups per trial like the production kernel
         std::vector<int> idx;
         for (int k = 0; k < n; k++)
             if (cfgs[k].variant == PRACH_VARIANT_NOMA_C) idx.push_back(k);
         if (!idx.empty()) {
-            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, 0, kernel_ms, upload_ms);
+            int minGroups = INT_MAX;
+            bool small = true;
+            for (int k : idx) { minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64); small = small && cfgs[k].nUE < (1 << 20) - 1; }
+            int G = (int)e->opt_cluster;
+            if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= 128 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
+            while (G > 1 && (size_t)G * idx.size() > 192) G /= 2;
+            if (!small) G = 1; // 20-bit granule fields
+            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, G, kernel_ms, upload_ms);
             if (rc != PRACH_OK) return rc;
         }
     }

@@ -6,9 +6,10 @@
  * bubble sort by channel gain, greedy >15 "dB" pairing onto 2 grants per sector, NOMA.c:194-324),
  * msg2Results (NOMA.c:449-498); every ms resourceRequestAllocation (NOMA.c:499-546), timers,
  * success count.  Pinned against the real NOMA program's stdout (tests/golden/noma_c.json) in
- * glibc mode; philox mode (per-UE counters; a pair's two draws come from the lower-gain UE's
- * counter) is the mode the GPU implements, because the rejection loops make the number of
- * rand() calls data dependent.
+ * glibc mode; philox mode (per-UE counters; a pair's two decode draws come from a per-(slot,
+ * sector, grant) counter of the pseudo-UE 0xFFFFFFFF, so that every workgroup of a cluster can
+ * evaluate them without exchanging state) is the mode the GPU implements, because the rejection
+ * loops make the number of rand() calls data dependent.
  */
 #define _GNU_SOURCE
 #include "prach_oracle.h"
@@ -37,6 +38,14 @@ typedef struct {
     oracle_rng *rng;
     nue_t *UE;
 } nctx_t;
+
+/* decode draws of a NOMA pair (NOMA.c:284-286): glibc: the global stream; philox: stateless per (slot, sector, grant) */
+static int pair_draw(nctx_t *c, int slot, int sector, int grant, int which) {
+    c->rng->consumed++;
+    if (c->rng->mode == ORACLE_RNG_GLIBC) return glibc_rand(&c->rng->g);
+    const uint32_t k = (uint32_t)(((slot * 6 + sector) * c->k->nGrantUL + grant) * 2 + which);
+    return philox_draw31(c->rng->seed, (uint32_t)c->k->nUE, 2u, 0xFFFFFFFFu, k);
+}
 
 static int ndraw(nctx_t *c, nue_t *u) {
     c->rng->consumed++;
@@ -136,10 +145,11 @@ static void preambleSectorCollisionDetection(nctx_t *c, int activeCheck, int tim
                         txUEs[i].idx = -1;
                         txUEs[j].idx = -1;
                         if (grantCheck[s] < nGrantUL) {
+                            const int gi = grantCheck[s];
                             grantCheck[s]++;
-                            double p = (double)ndraw(c, &user[rx[0]]) / (double)2147483647;
+                            double p = (double)pair_draw(c, time / k->accessTime, s, gi, 0) / (double)2147483647;
                             if (p < 0.3) {
-                                int randomUE = ndraw(c, &user[rx[0]]) % 2;
+                                int randomUE = pair_draw(c, time / k->accessTime, s, gi, 1) % 2;
                                 user[rx[randomUE]].msg2 = 1;
                             } else {
                                 user[rx[0]].msg2 = 1;

@@ -91,3 +91,24 @@ def test_gpu_noma_full_size_and_statistics(pkg, ob, engine):
     with pytest.raises(pkg.PrachError) as ei:
         engine.run_trials([bad])
     assert ei.value.status == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 4, 32])
+def test_gpu_noma_cluster_sizes(pkg, ob, engine, G):
+    """The NOMA kernel with G workgroups per trial (one granule exchange per 5 ms slot) == the oracle for every G;
+    also an early-finishing light-load trial (every UE succeeds: exit subframe of NOMA.c:707-710)."""
+    engine.set("cluster", G)
+    try:
+        for nUE, kw in ((20000, {}), (64, dict(nGrantUL=30)), (8, dict(nGrantUL=30))):
+            cfg = pkg.make_cfg(nUE, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=11, **kw)
+            (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+            ocfg = ob.make_noma_cfg(nUE, **kw)
+            ores, oues = ob.noma_run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, 11))
+            assert (res.nSuccessUE, res.sumTimer, res.preambleTxCount, res.failCounts, res.draws, res.time_exit) == \
+                   (ores.nSuccessUE, ores.delay, ores.nTxP, ores.raFailedUEs, ores.draws, ores.time_exit), (G, nUE)
+            a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16)
+            b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
+            assert (a == b).all(), (G, nUE)
+    finally:
+        engine.set("cluster", 0)
