@@ -28,6 +28,7 @@
 namespace prach {
 
 // LDS carve-up (dynamic shared memory, 16-byte aligned base; prach_device.h sizes)
+constexpr int DEADW_T = 1024; // 32768 groups = 2M UEs; larger trials simply do not skip
 struct Lds {
     Event *evl;    // [EVCAP]
     int *sidx;     // [SCAP]
@@ -44,6 +45,7 @@ struct Lds {
     int *gsmle;    // [nP]
     int *fcall;    // [nP] index of the first caller on the bucket this subframe (INT_MAX: none)
     int *lcall;    // [nP] index of the last caller (-1: none)
+    unsigned *dead; // [DEADW_T] bitmap of 64-UE groups in which every UE has finished (skipped by every pass)
 };
 enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_FINS, S_NS, S_NRC, S_NPOST, S_STATUS, S_PTC, S_FC, S_ND_LO,
        S_SUMT_LO = 16 /* 64-bit at [16,17] */, S_ND64 = 18 /* 64-bit at [18,19] */ };
@@ -66,10 +68,11 @@ __device__ __forceinline__ Lds carve(char *smem, int nP) {
     L.gsmle = ip; ip += nP;
     L.fcall = ip; ip += nP;
     L.lcall = ip; ip += nP;
+    L.dead = reinterpret_cast<unsigned *>(ip); ip += DEADW_T;
     return L;
 }
 size_t trial_kernel_lds_bytes(int nP) {
-    return sizeof(Event) * EVCAP + sizeof(int) * (SCAP + RCCAP + 64 + NW + NW + 16 + NW + 3 * NW * nP + 5 * nP);
+    return sizeof(Event) * EVCAP + sizeof(int) * (SCAP + RCCAP + 64 + NW + NW + 16 + NW + 3 * NW * nP + 5 * nP + DEADW_T);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -83,6 +86,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
                                         const int activeCheck, const unsigned long long stepbase) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nP = P.nP, aT = P.aT;
+    const FastMod fmP = make_fastmod(nP), fmB = make_fastmod(P.backoff), fmA = make_fastmod(aT), fm5 = make_fastmod(5);
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
     const int groups = (activeCheck + 63) >> 6;
     const int gper = (groups + NW - 1) / NW;
@@ -98,6 +102,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
     const int tp = t - 1;
 
     for (int g = g0; g < g1; g++) {
+        if (g < DEADW_T * 32 && ((L.dead[g >> 5] >> (g & 31)) & 1u)) continue; // every UE of the group has finished
         const int i = g * 64 + lane;
         const bool valid = i < activeCheck;
         int4 r = make_int4(-1, 0, 0, 0);
@@ -118,7 +123,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
                 } else if (pend == PEND_RESET) {
                     const int q = bo, tmp = tx;
                     const int bumped = L.fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
-                    const int x = slot_align(tp + bumped + tmp, aT);
+                    const int x = slot_align_fm(tp + bumped + tmp, fmA);
                     if (x == tp) { bo = 0; tx = tp + 1; } // re-joined and called, no grant
                     else { tx = x; bo = x; }
                 } else if (pend == PEND_PASSIVE) {
@@ -172,7 +177,10 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
 
         // nothing to do for the whole wavefront?  (waiting / finished / not yet arrived UEs)
         const bool busy = isM1 || m3due;
-        if (!__any(busy || dirty)) continue;
+        if (!__any(busy || dirty)) {
+            if (g < DEADW_T * 32 && __all(i >= P.nUE || act == ACT_DONE) && lane == 0) atomicOr(&L.dead[g >> 5], 1u << (g & 31));
+            continue;
+        }
 
         // ---- draws ----
         int d1 = 0, d2 = 0;
@@ -203,7 +211,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
         const bool member_pre = isM1 && tx == t && pre != 0; // matched by a preambleCollision scan right now
         int evtype = 0, evp = 0, evq = 0;
         if (firstsel) { // Beta.c:231-239
-            pre = d1 % nP + 1; rar = 0; mrc = 0; bo = 0;
+            pre = fastmod(d1, fmP) + 1; rar = 0; mrc = 0; bo = 0;
             P.ptc[i] = 1;
             if (withnoma) P.fcnt[i] = 0;
             if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = pre - 1; }
@@ -219,8 +227,8 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
             dirty = true;
             if (reset) { // Beta.c:250-281
                 if (withnoma) { c_contf++; P.fcnt[i] = P.fcnt[i] + 1; }
-                const int newp = d1 % nP;
-                const int tmp = d2 % P.backoff;
+                const int newp = fastmod(d1, fmP);
+                const int tmp = fastmod(d2, fmB);
                 rar = 0; mrc = 0; tb = t;
                 P.ptc[i] = 1; P.ftt[i] = t + 1;
                 pre = newp + 1;
@@ -228,15 +236,15 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
                     pend = PEND_RESET; tx = tmp; bo = oldp;
                     if (tmp == 0 && aT > 1 && t % aT == 1) { evtype = EV_RESETCAND; evp = newp; evq = oldp; }
                 } else {
-                    tx = slot_align(tx + tmp, aT);
+                    tx = slot_align_fm(tx + tmp, fmA);
                     bo = enc_backoff(tx - t, t);
                     if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = newp; }
                 }
             } else if (retx) { // Beta.c:282-308
                 rar = 0; mrc++;
                 P.ptc[i] = P.ptc[i] + 1;
-                const int tmp = d1 % P.backoff;
-                tx = slot_align(t + tmp, aT);
+                const int tmp = fastmod(d1, fmB);
+                tx = slot_align_fm(t + tmp, fmA);
                 bo = enc_backoff(tx - t, t);
                 P.stt[i] = tx;
                 if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = oldp; } // the "late joiner"
@@ -251,11 +259,11 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
             dirty = true;
         } else if (m3to) { // Msg3 timeout, Beta.c:384-410
             c_contf++;
-            const int tmp = d1 % P.backoff;
-            tx = slot_align(tx + tmp, 5); // hard-coded accessTime = 5, Beta.c:389
+            const int tmp = fastmod(d1, fmB);
+            tx = slot_align_fm(tx + tmp, fm5); // hard-coded accessTime = 5, Beta.c:389
             act = ACT_M1;
             bo = enc_backoff(tx - t, t);
-            pre = d2 % nP + 1;
+            pre = fastmod(d2, fmP) + 1;
             tb = t; rar = 0; mrc = 0; conn = 0;
             if (withnoma) P.fcnt[i] = P.fcnt[i] + 1;
             if (tx == t) { pend = PEND_RJOIN; evtype = EV_RJOIN; evp = pre - 1; }
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__res
     for (int k = tid; k < NW * nP; k += WG_THREADS) { L.wavehist[k] = 0; L.smidx[k] = INT_MAX; L.smle[k] = 0; }
     for (int k = tid; k < nP; k += WG_THREADS) { L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.total[k] = 0; L.gsm[k] = INT_MAX; L.gsmle[k] = 0; }
     if (tid < 64) L.scal[tid] = 0;
+    for (int k = tid; k < DEADW_T; k += WG_THREADS) L.dead[k] = 0;
     if (tid < NW) { L.evcnt[tid] = 0; L.wdraws[tid] = 0; }
     __syncthreads();
 
