@@ -270,3 +270,40 @@ def test_cli_philox_grid_in_one_call(pkg, ob, engine, tmp_path):
             assert (d / f"{seed}_54_{n}_Results.txt").read_bytes() == ob.format_results(ocfg, ores)
             assert (d / f"{seed}_54_UE{n:05d}_Logs.txt").read_bytes() == ob.format_logs(oues, n)
             k += 1
+
+
+def test_sharded_sweep_driver_two_ranks(pkg, ob, tmp_path):
+    """sweep.py (BASELINE config 5 shape) with 2 ranks rehearsed on one GPU (gloo): sharding + ONE all-reduce +
+    row gather + results.csv; the aggregate equals the oracle's trial by trial."""
+    import json
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "5g-nr-randomaccess_amd", "sweep.py"), "--times", "3", "--sweep",
+           "3000:9000:3000", "--out", str(tmp_path), "--backend", "gloo", "--same-device"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    summary = json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
+    texts = {n: [] for n in (3000, 6000, 9000)}
+    succ = {n: 0 for n in texts}
+    upd = 0
+    for s in range(3):
+        for n in texts:
+            ocfg = ob.make_cfg(n, variant=0)
+            ores, _ = ob.run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, s), want_ues=False)
+            texts[n].append(ob.format_results(ocfg, ores).decode() + "0.000000")
+            succ[n] += ores.nSuccessUE
+            upd += n * ores.steps
+    assert summary["updates"] == upd
+    assert summary["success_ratio"] == {str(n): succ[n] / (3 * n) for n in texts}
+    assert (tmp_path / "results.csv").read_bytes() == pkg.results_csv([texts[n] for n in (3000, 6000, 9000)])
+
+
+def test_beyond_reference_sizes(pkg, ob, engine):
+    """nUE = 250 000 (2.5x the reference's largest point): still bit-exact vs the oracle, and one workgroup cluster
+    per trial still covers it (interleaved ownership scales with nUE, not with a per-CU capacity)."""
+    n = 250000
+    cfg = pkg.make_cfg(n, variant=0, rng_mode=pkg.RNG_PHILOX, seed=3, max_steps=4000)
+    (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+    ores, oues = ob.run_trial(ob.make_cfg(n, variant=0, max_steps=4000), ob.Rng(ob.RNG_PHILOX, 3))
+    assert_same(pkg, res, logs, ores, oues, "250k")
