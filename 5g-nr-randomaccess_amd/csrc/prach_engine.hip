@@ -36,6 +36,7 @@ struct prach_engine {
     int64_t opt_cluster = 0;       // workgroups per trial for the Philox cluster kernel (0 = auto)
     int64_t opt_legacy = 0;        // 1: run Philox trials on the one-workgroup trial_kernel as well
     int last_G = 0;
+    int num_cus = 256;            // co-residency budget of the cluster kernels: one 1024-thread workgroup per CU
 };
 
 namespace {
@@ -111,6 +112,7 @@ int prach_engine_create(int device, prach_engine **out) {
     }
     prach_engine *e = new prach_engine();
     e->device = device;
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
@@ -322,8 +324,9 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
             bool small = true;
             for (int k : idx) { minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64); small = small && cfgs[k].nUE < (1 << 20) - 1; }
             int G = (int)e->opt_cluster;
-            if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= 128 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
-            while (G > 1 && (size_t)G * idx.size() > 192) G /= 2;
+            const size_t resident = (size_t)e->num_cus * 3 / 4;
+            if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 + resident / 6 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
+            while (G > 1 && (size_t)G * idx.size() > resident) G /= 2;
             if (!small) G = 1; // 20-bit granule fields
             int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, G, kernel_ms, upload_ms);
             if (rc != PRACH_OK) return rc;
@@ -342,8 +345,9 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
             int minGroups = INT_MAX;
             for (int k : idx) minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
             int G = (int)e->opt_cluster;
-            if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= 128 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
-            while (G > 1 && (size_t)G * idx.size() > 192) G /= 2; // every cluster must be co-resident (256 CUs)
+            const size_t resident = (size_t)e->num_cus * 3 / 4; // every cluster must be co-resident: <= one workgroup per CU, with margin
+            if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 + resident / 6 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
+            while (G > 1 && (size_t)G * idx.size() > resident) G /= 2;
             int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, G, kernel_ms, upload_ms);
             if (rc != PRACH_OK) return rc;
             std::vector<int> again; // a per-subframe capacity of the cluster kernel was exceeded: exact rerun on trial_kernel

@@ -370,7 +370,7 @@ size_t prach_results_csv_row(const double acc[6], int nseeds, char *buf, size_t 
     for (int i = 0; i < 6; i++) {
         double v = acc[i] / (double)nseeds;       /* lists/len(seedNumber) */
         v = rint(v * 1000.0) / 1000.0;             /* np.around(., 3): multiply, rint (half to even), divide */
-        char f[64];
+        char f[80];
         py_float_repr(v, f, sizeof f);
         n += snprintf(tmp + n, sizeof tmp - n, "%s%s", i ? "," : "", f);
     }
