@@ -49,7 +49,7 @@ constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups)
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 enum { C_NSUCC = 0, C_COLL, C_TXOP, C_CONTF, C_NS, C_NRC, C_NRJ, C_STATUS, C_NEV, C_NCAND, C_OVF, C_NSUCCTOT, C_NTOT,
-       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20 };
+       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20, C_GTOT = 21 };
 
 struct CLds {
     int2 *gev;    // [EVCAPC] gathered events of all workgroups
@@ -61,11 +61,14 @@ struct CLds {
     int *bins;    // [GBINS] grant selection: singleton callers per index bin (then exclusive prefix)
     int *wtot;    // [NW]
     int *hist, *mloc, *total, *fcall, *lcall, *nlv, *fie; // [nP] each
+    int *gsum;    // [GSCAP] glibc mode: rand() calls of every 64-UE group in this subframe's UE loop
+    int *gpre;    // [GSCAP] their exclusive prefix in index order
 };
 constexpr int GBINS = 1024;
+constexpr int GSCAP = 4096; // glibc mode on the cluster kernel: at most 4096 groups (262 144 UEs)
 constexpr int MAXG = 64; // the gather's header phase is one wavefront: lane = workgroup
 
-__device__ __forceinline__ CLds ccarve(char *smem, int nP) {
+__device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc) {
     CLds L;
     L.gev = reinterpret_cast<int2 *>(smem);
     int *ip = reinterpret_cast<int *>(smem + sizeof(int2) * EVCAPC);
@@ -78,6 +81,8 @@ __device__ __forceinline__ CLds ccarve(char *smem, int nP) {
     L.wtot = ip; ip += NW;
     L.hist = ip; ip += nP; L.mloc = ip; ip += nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
     L.lcall = ip; ip += 2 * nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
+    L.gsum = ip; L.gpre = ip + GSCAP; // only carved (and only touched) in glibc mode
+    (void)glibc;
     return L;
 }
 
@@ -126,12 +131,15 @@ __device__ __forceinline__ long long *gr_of(const Ctx &C, int parity, int wg) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass over the groups this workgroup owns.  FINAL: only the deferred apply of the last subframe.
+// pass over the groups this workgroup owns.  MODE 0: fused apply + activate + select (Philox);
+// glibc mode splits it: MODE 1 apply + activate + per-group draw counts, MODE 2 select with stream offsets;
+// MODE 3: only the deferred apply of the last subframe.
 // ---------------------------------------------------------------------------------------------
-template <bool FINAL>
+template <int MODE>
 __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall, const int *lcall,
                                              const int t, const int prevAC,
-                                             const int activeCheck, long long *mbev, const unsigned tag) {
+                                             const int activeCheck, long long *mbev, const unsigned tag, const unsigned long long stepbase) {
+    constexpr bool FINAL = MODE == 3;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int aT = P.aT, nUE = P.nUE;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
@@ -154,7 +162,7 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
     unsigned ndn = 0;
     if (jn >= 0) {
         const int in = (C.b + C.G * jn) * 64 + lane;
-        if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (!FINAL) ndn = P.nd[in]; }
+        if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (MODE == 0) ndn = P.nd[in]; }
     }
     while (jn >= 0) {
         const int j = jn;
@@ -168,14 +176,14 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
         ndn = 0;
         if (jn >= 0) {
             const int in = (C.b + C.G * jn) * 64 + lane;
-            if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (!FINAL) ndn = P.nd[in]; }
+            if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (MODE == 0) ndn = P.nd[in]; }
         }
         bool nd_dirty = false;
         UeState u = unpack(r);
         bool dirty = false;
 
         // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
-        if (u.pend != PEND_NONE) {
+        if (MODE != 2 && u.pend != PEND_NONE) {
             if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
                 u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
                 if (u.pend == PEND_RESET) u.bo = 0;
@@ -200,10 +208,10 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
             continue;
         }
         // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
-        if (valid && i >= prevAC) {
+        if (MODE != 2 && valid && i >= prevAC) {
             u.act = ACT_M1; u.tx = t + 1; u.tb = t;
             P.ftt[i] = t + 1;
-            if (withnoma) { ndc = 2; nd_dirty = true; }
+            if (MODE == 0 && withnoma) { ndc = 2; nd_dirty = true; }
             dirty = true;
         }
 
@@ -219,6 +227,13 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
         const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
         const bool busy = isM1 || m3due;
 
+        if (MODE == 1) { // glibc: this group's rand() calls in the UE loop of subframe t (own pre-step state only)
+            const int gs = __popcll(__ballot(need >= 1)) + __popcll(__ballot(need == 2));
+            if (lane == 0) L.gsum[g] = gs;
+            if (dirty) P.rec[i] = pack(u);
+            continue;
+        }
+
         if (!__any(busy || dirty)) {
             // nothing happens in this group; retire it for good once every UE in it has finished
             if (__all(i >= nUE || u.act == ACT_DONE) && lane == 0) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
@@ -226,7 +241,16 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
         }
 
         int d1 = 0, d2 = 0;
-        if (__any(need > 0)) {
+        if (MODE == 2) { // the reference's own stream: position = draws before this subframe's UE loop + index-ordered prefix
+            if (__any(need > 0)) {
+                int x = need;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+                const unsigned long long o = stepbase + (unsigned long long)L.gpre[g] + (unsigned long long)(x - need);
+                if (need > 0) d1 = P.stream[o];
+                if (need > 1) d2 = P.stream[o + 1];
+            }
+        } else if (__any(need > 0)) {
             const unsigned k = ndc;
             d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, (unsigned)P.variant);
             if (__any(need > 1))
@@ -409,11 +433,12 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fca
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
+template <bool GLIBC>
 __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = blockIdx.x % nT, b = blockIdx.x / nT;
     const TrialDev P = params[T];
-    const CLds L = ccarve(smem, P.nP);
+    const CLds L = ccarve(smem, P.nP, GLIBC);
     const int tid = threadIdx.x;
     const int nUE = P.nUE, nP = P.nP, aT = P.aT;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
@@ -440,11 +465,13 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     }
     if (tid < 64) L.scal[tid] = 0;
     for (int k = tid; k < DEADW; k += WG_THREADS) L.dead[k] = 0;
+    if (GLIBC) for (int k = tid; k < GSCAP; k += WG_THREADS) { L.gsum[k] = 0; L.gpre[k] = 0; }
     __syncthreads();
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = P.stop;
     unsigned long long steps = 0;
-    int status = (lgroups > DEADW * 32) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (lgroups > DEADW * 32 || (GLIBC && totgroups > GSCAP)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    unsigned long long base = 0; // glibc: rand() calls consumed so far (relative to the stream window)
 #ifdef PRACH_STAMPS
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     unsigned long long statN = 0, maxN = 0, statRC = 0, statNS = 0, maxNS = 0;
@@ -465,7 +492,56 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         int *const fcallA = L.fcall + parity * nP, *const lcallA = L.lcall + parity * nP;
         int *const fcallB = L.fcall + (parity ^ 1) * nP, *const lcallB = L.lcall + (parity ^ 1) * nP;
 
-        cluster_pass<false>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag);
+        if (GLIBC) {
+            // glibc mode: every draw's position in the reference's rand() stream = draws of earlier subframes + the
+            // activation draws of this one (WithNOMA:393-394) + an index-ordered prefix of per-UE draw counts.
+            // Pass X counts per 64-UE group; the counts of all groups are exchanged (2 per granule) and scanned.
+            const unsigned long long actdraws = withnoma ? 2ull * (unsigned long long)(activeCheck - prevAC) : 0ull;
+            const int ngroups_t = (activeCheck + 63) >> 6;
+            cluster_pass<1>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+            __syncthreads();
+            if (G > 1) {
+                const int nq = (lgroups + 1) >> 1;
+                long long *const mine = mygr + 1 + nP + C.evw;
+                for (int q = tid; q < nq; q += WG_THREADS) {
+                    const int g0 = b + G * (2 * q), g1 = b + G * (2 * q + 1);
+                    st_sc1_64(mine + q, mk_granule(g0 < totgroups ? (unsigned)L.gsum[g0] : 0u, g1 < totgroups ? (unsigned)L.gsum[g1] : 0u, tag));
+                }
+                for (int k = tid; k < G * nq; k += WG_THREADS) {
+                    const int wg = k / nq, q = k - wg * nq;
+                    if (wg == b) continue;
+                    const long long g_ = wait_granule(gr_of(C, parity, wg) + 1 + nP + C.evw + q, tag, &L.scal[C_STATUS]);
+                    const int g0 = wg + G * (2 * q), g1 = wg + G * (2 * q + 1);
+                    if (g0 < totgroups) L.gsum[g0] = (int)((unsigned)g_ & 0xFFFFFu);
+                    if (g1 < totgroups) L.gsum[g1] = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu);
+                }
+                __syncthreads();
+            }
+            { // block-wide exclusive prefix over the arrived groups (4 consecutive groups per thread)
+                int v[4], sum = 0;
+#pragma unroll
+                for (int u_ = 0; u_ < 4; u_++) { const int g = tid * 4 + u_; v[u_] = g < ngroups_t ? L.gsum[g] : 0; sum += v[u_]; }
+                int x = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((tid & 63) >= d) x += y; }
+                if ((tid & 63) == 63) L.wtot[tid >> 6] = x;
+                __syncthreads();
+                int add = 0;
+                for (int k = 0; k < (tid >> 6); k++) add += L.wtot[k];
+                int run = x - sum + add;
+#pragma unroll
+                for (int u_ = 0; u_ < 4; u_++) { const int g = tid * 4 + u_; if (g < GSCAP) L.gpre[g] = run; run += v[u_]; }
+                if (tid == WG_THREADS - 1) L.scal[C_GTOT] = run;
+            }
+            __syncthreads();
+            if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
+            const unsigned long long tot = actdraws + (unsigned long long)L.scal[C_GTOT];
+            if (base + tot > P.stream_len) { status = PRACH_ERR_STREAM; time_exit = t; break; } // engine retries with a larger window
+            cluster_pass<2>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, base + actdraws);
+            base += tot;
+        } else {
+            cluster_pass<0>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+        }
         __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
         STAMP(0);
 
@@ -677,7 +753,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }
     __syncthreads();
-    if (status == PRACH_OK && tlast >= 0) cluster_pass<true>(P, L, C, FM, L.fcall + (tlast & 1) * nP, L.lcall + (tlast & 1) * nP, tlast + 1, activeCheck, activeCheck, nullptr, 0u);
+    if (status == PRACH_OK && tlast >= 0) cluster_pass<3>(P, L, C, FM, L.fcall + (tlast & 1) * nP, L.lcall + (tlast & 1) * nP, tlast + 1, activeCheck, activeCheck, nullptr, 0u, 0ull);
     __syncthreads();
 
     // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of the owned UEs
@@ -718,7 +794,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     if (tid == 0) { // DevResult was zeroed by the engine before the launch
         DevResult *o = P.out;
         atomicAdd(reinterpret_cast<unsigned long long *>(&o->sumTimer), *reinterpret_cast<unsigned long long *>(&L.scal[C_SUMT]));
-        atomicAdd(&o->draws, *reinterpret_cast<unsigned long long *>(&L.scal[C_ND]));
+        if (GLIBC) { if (b == 0) atomicAdd(&o->draws, base); }
+        else atomicAdd(&o->draws, *reinterpret_cast<unsigned long long *>(&L.scal[C_ND]));
         atomicAdd(&o->ptcSum, L.scal[C_PTC]);
         atomicAdd(&o->fcSum, L.scal[C_FC]);
         atomicAdd(&o->nSuccess, L.scal[C_NSUCC]);
@@ -739,15 +816,18 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     }
 }
 
-size_t cluster_kernel_lds_bytes(int nP) {
-    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 9 * nP);
+size_t cluster_kernel_lds_bytes(int nP, bool glibc) {
+    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 9 * nP + (glibc ? 2 * GSCAP : 0));
 }
 
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream) {
-    const size_t lds = cluster_kernel_lds_bytes(maxP);
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, hipStream_t stream) {
+    const bool glibc = rng_mode == PRACH_RNG_GLIBC;
+    const size_t lds = cluster_kernel_lds_bytes(maxP, glibc);
+    const void *fn = glibc ? reinterpret_cast<const void *>(&cluster_kernel<true>) : reinterpret_cast<const void *>(&cluster_kernel<false>);
+    hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(cluster_kernel, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
+    if (glibc) hipLaunchKernelGGL(cluster_kernel<true>, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
+    else hipLaunchKernelGGL(cluster_kernel<false>, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
     return hipGetLastError();
 }
 

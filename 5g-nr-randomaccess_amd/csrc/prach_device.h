@@ -81,8 +81,9 @@ constexpr int RCCAP = 256;          // reset-cycle re-join candidates per subfra
 
 size_t trial_kernel_lds_bytes(int nP);
 hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream);
-size_t cluster_kernel_lds_bytes(int nP);
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
+size_t cluster_kernel_lds_bytes(int nP, bool glibc);
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, hipStream_t stream);
+constexpr int CLUSTER_GLIBC_MAX_UE = 4096 * 64; // glibc mode on the cluster kernel: per-group draw counts live in LDS
 constexpr int CLUSTER_MAX_G = 64;
 size_t noma_kernel_lds_bytes(int nP);
 hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);

@@ -69,7 +69,8 @@ TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t
     L.evw = 0; L.mbstride = 0; L.mbox = L.bar = L.cand = 0;
     if (G > 0) { // cluster kernel: mailboxes, arrival counter, early-leaver candidate scratch
         L.evw = G == 1 ? 4096 : 512;
-        L.mbstride = (int)align_up((size_t)2 * (1 + c.nPreamble + L.evw), 4); // 8-byte granules: header, buckets, events
+        const size_t lgroups = ((n + 63) / 64 + (size_t)G - 1) / (size_t)G;
+        L.mbstride = (int)align_up((size_t)2 * (1 + c.nPreamble + L.evw + (lgroups + 1) / 2), 4); // 8-byte granules: header, buckets, events, (glibc) group draw counts
         if (c.variant == PRACH_VARIANT_NOMA_C) L.mbstride = (int)align_up((size_t)2 * (1 + 6 * c.nPreamble), 4); // header + 6 x nP bins
         L.mbox = take(4 * (size_t)2 * G * L.mbstride);
         L.bar = take(256);
@@ -240,7 +241,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
 
     HIPCHK(hipEventRecord(e->ev0, e->stream));
     if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
-    else if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
+    else if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, rng_mode, e->stream));
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -337,23 +338,33 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
         for (int k = 0; k < n; k++)
             if (cfgs[k].rng_mode == mode && cfgs[k].variant != PRACH_VARIANT_NOMA_C) idx.push_back(k);
         if (idx.empty()) continue;
-        bool cluster_ok = mode == PRACH_RNG_PHILOX && !e->opt_legacy;
-        for (int k : idx) cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
+        bool cluster_ok = !e->opt_legacy;
+        for (int k : idx) {
+            cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
+            if (mode == PRACH_RNG_GLIBC) cluster_ok = cluster_ok && cfgs[k].nUE <= CLUSTER_GLIBC_MAX_UE;
+        }
         if (cluster_ok) {
             // production path: cluster kernel, G workgroups per trial (all clusters must be co-resident:
-            // at most one 1024-thread workgroup per CU is assumed, 256 CUs)
+            // at most one 1024-thread workgroup per CU)
             int minGroups = INT_MAX;
             for (int k : idx) minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
             int G = (int)e->opt_cluster;
             const size_t resident = (size_t)e->num_cus * 3 / 4; // every cluster must be co-resident: <= one workgroup per CU, with margin
             if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 + resident / 6 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
             while (G > 1 && (size_t)G * idx.size() > resident) G /= 2;
-            int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, G, kernel_ms, upload_ms);
-            if (rc != PRACH_OK) return rc;
-            std::vector<int> again; // a per-subframe capacity of the cluster kernel was exceeded: exact rerun on trial_kernel
-            for (int k : idx)
-                if (results[k].status == PRACH_ERR_INTERNAL) again.push_back(k);
-            idx.swap(again);
+            std::vector<int> todo = idx, fallback;
+            for (int attempt = 0; !todo.empty(); attempt++) {
+                if (attempt > 6) return PRACH_ERR_STREAM;
+                int rc = run_group(e, cfgs, todo.data(), (int)todo.size(), results, ue_logs, attempt, G, kernel_ms, upload_ms);
+                if (rc != PRACH_OK) return rc;
+                std::vector<int> again;
+                for (int k : todo) {
+                    if (results[k].status == PRACH_ERR_STREAM) again.push_back(k);         // glibc: draw-stream window ran out: larger one
+                    else if (results[k].status == PRACH_ERR_INTERNAL) fallback.push_back(k); // a per-subframe capacity was exceeded:
+                }                                                                              // exact rerun on trial_kernel
+                todo.swap(again);
+            }
+            idx.swap(fallback);
             if (idx.empty()) continue;
         }
         int attempt = 0;

@@ -307,3 +307,16 @@ def test_beyond_reference_sizes(pkg, ob, engine):
     (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
     ores, oues = ob.run_trial(ob.make_cfg(n, variant=0, max_steps=4000), ob.Rng(ob.RNG_PHILOX, 3))
     assert_same(pkg, res, logs, ores, oues, "250k")
+
+
+def test_legacy_kernel_glibc_mode(pkg, ob, engine):
+    """The one-workgroup kernel (exact fallback) in glibc mode, forced."""
+    engine.set("legacy", 1)
+    try:
+        cfg = pkg.make_cfg(12000, variant=0, rng_mode=pkg.RNG_GLIBC, seed=6)
+        (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+        assert engine.timing().workgroups == 1
+    finally:
+        engine.set("legacy", 0)
+    ores, oues = ob.run_trial(ob.make_cfg(12000, variant=0), ob.Rng(ob.RNG_GLIBC, 6))
+    assert_same(pkg, res, logs, ores, oues, "legacy glibc")
