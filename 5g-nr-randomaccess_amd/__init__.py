@@ -88,6 +88,7 @@ def lib():
         L.prach_arrival_schedule.argtypes = [C.POINTER(PrachCfg), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32)]
         L.prach_glibc_stream.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
         L.prach_glibc_stream.restype = None
+        L.prach_device_glibc_stream.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
         L.prach_strerror.argtypes = [C.c_int]
         L.prach_strerror.restype = C.c_char_p
         L.prach_format_logs.argtypes = [C.POINTER(PrachUeLog), C.c_int, C.c_char_p, C.c_size_t]
@@ -112,7 +113,7 @@ EXPORTS = ("prach_engine_create", "prach_engine_destroy", "prach_engine_set", "p
            "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_arrival_schedule", "prach_glibc_stream",
            "prach_strerror", "prach_format_logs", "prach_format_results", "prach_format_stdout",
            "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line",
-           "prach_results_csv_accumulate", "prach_results_csv_row")
+           "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream")
 
 
 def make_cfg(nUE, variant=VARIANT_BETA_C, uniform=0, rng_mode=RNG_GLIBC, seed=0, stream_offset=0, **kw) -> PrachCfg:
@@ -167,6 +168,14 @@ class Engine:
         if rc != OK:
             raise PrachError(rc, "(prach_run_trials)")
         return list(res), logs
+
+    def device_glibc_stream(self, seed, first, n):
+        import numpy as np
+        out = np.empty(n, dtype=np.int32)
+        rc = lib().prach_device_glibc_stream(self._h, seed, first, n, out.ctypes.data)
+        if rc != OK:
+            raise PrachError(rc, "(prach_device_glibc_stream)")
+        return out
 
     def timing(self) -> PrachTiming:
         t = PrachTiming()

@@ -46,6 +46,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, bar, cand, end;
     size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0;
+    size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
     int evw, mbstride;
 };
@@ -63,6 +64,8 @@ TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t
     L.sched = take(4 * L.sched_len);
     L.stream_len = stream_len;
     L.stream = take(4 * (stream_len + 2));
+    L.nchunks = (stream_len + STREAM_CHUNK - 1) / STREAM_CHUNK;
+    L.seeds = take(4 * 31 * (L.nchunks + 1));
     L.logs = want_logs ? take(sizeof(prach_ue_log) * n) : 0;
     L.timers = take(4 * n);
     L.out = take(sizeof(DevResult));
@@ -139,6 +142,27 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     return PRACH_ERR_ARG;
 }
 
+int prach_device_glibc_stream(prach_engine *e, uint32_t seed, uint64_t first, uint64_t n, int32_t *out) {
+    if (!e || !out || n == 0) return PRACH_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t nchunks = (n + STREAM_CHUNK - 1) / STREAM_CHUNK;
+    const size_t need = align_up(4 * 31 * nchunks, 256) + 4 * (n + 2);
+    if (need > e->arena_cap) {
+        if (e->arena) HIPCHK(hipFree(e->arena));
+        e->arena = nullptr; e->arena_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->arena), need));
+        e->arena_cap = need;
+    }
+    std::vector<uint32_t> seeds(31 * nchunks);
+    prach_internal_glibc_seeds(seed, first, nchunks, STREAM_CHUNK, seeds.data());
+    HIPCHK(hipMemcpy(e->arena, seeds.data(), 4 * 31 * nchunks, hipMemcpyHostToDevice));
+    int *dout = reinterpret_cast<int *>(e->arena + align_up(4 * 31 * nchunks, 256));
+    HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(e->arena), dout, n, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
+    return PRACH_OK;
+}
+
 int prach_last_timing(const prach_engine *e, prach_timing *out) {
     if (!e || !out) return PRACH_ERR_ARG;
     *out = e->last;
@@ -171,7 +195,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     auto t0 = std::chrono::steady_clock::now();
     std::vector<TrialDev> td(m);
     std::vector<int32_t> sched;
-    std::vector<int32_t> strm;
+    std::vector<uint32_t> seeds;
     std::vector<int32_t> nAccess(m, 0);
     for (int k = 0; k < m; k++) {
         const prach_cfg &c = cfgs[idx[k]];
@@ -228,9 +252,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             d.n_nd0 = reinterpret_cast<const unsigned *>(A + L.n_nd0);
         }
         if (rng_mode == PRACH_RNG_GLIBC) {
-            strm.resize(L.stream_len);
-            prach_glibc_stream((uint32_t)c.seed, c.stream_offset, L.stream_len, strm.data());
-            HIPCHK(hipMemcpyAsync(A + L.stream, strm.data(), 4 * L.stream_len, hipMemcpyHostToDevice, e->stream));
+            // the reference's rand() stream window [stream_offset, +stream_len): the host only jumps ahead (31-word window
+            // per chunk, cached matrix powers); the values themselves are generated on the device inside the timed region
+            seeds.resize(31 * (L.nchunks + 1));
+            prach_internal_glibc_seeds((uint32_t)c.seed, c.stream_offset, L.nchunks, STREAM_CHUNK, seeds.data());
+            HIPCHK(hipMemcpyAsync(A + L.seeds, seeds.data(), 4 * 31 * L.nchunks, hipMemcpyHostToDevice, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
         }
     }
@@ -240,6 +266,10 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     upload_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
 
     HIPCHK(hipEventRecord(e->ev0, e->stream));
+    if (rng_mode == PRACH_RNG_GLIBC)
+        for (int k = 0; k < m; k++)
+            HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(e->arena + lay[k].seeds), reinterpret_cast<int *>(e->arena + lay[k].stream),
+                                       (unsigned long long)lay[k].stream_len, e->stream));
     if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
     else if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, rng_mode, e->stream));
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));

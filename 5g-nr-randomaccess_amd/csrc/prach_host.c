@@ -188,6 +188,78 @@ size_t prach_format_noma_line(const prach_cfg *c, const prach_result *r, char *b
     return (size_t)n;
 }
 
+/* ---- glibc rand() stream: jump-ahead (for the device-side generator) ------------------------------
+ * Linear form of the TYPE_3 generator: r[0..30] from the seed, r[31..33] = r[0..2],
+ * r[i] = r[i-31] + r[i-3] (mod 2^32) for i >= 34, and the k-th rand() = r[344+k] >> 1.  A window
+ * W_n = (r[n-30] .. r[n]) advances by the 31x31 companion matrix A over Z/2^32, so W_{n+D} = A^D W_n:
+ * powers A^(2^j) are cached, a jump costs <= 40 mat-vecs.  prach_internal_glibc_seeds returns, for each
+ * chunk c of `chunk` outputs starting at output `first`, the window that precedes its first value. */
+typedef struct { uint32_t m[31][31]; } lfg_mat;
+static lfg_mat lfg_pow2[48];
+static int lfg_pow2_ready = 0;
+
+static void lfg_matmul(const lfg_mat *a, const lfg_mat *b, lfg_mat *out) {
+    for (int i = 0; i < 31; i++)
+        for (int j = 0; j < 31; j++) {
+            uint32_t acc = 0;
+            for (int k = 0; k < 31; k++) acc += a->m[i][k] * b->m[k][j];
+            out->m[i][j] = acc;
+        }
+}
+static void lfg_matvec(const lfg_mat *a, const uint32_t *w, uint32_t *out) {
+    for (int i = 0; i < 31; i++) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 31; k++) acc += a->m[i][k] * w[k];
+        out[i] = acc;
+    }
+}
+static void lfg_init_pows(void) {
+    if (lfg_pow2_ready) return;
+    memset(&lfg_pow2[0], 0, sizeof(lfg_mat));
+    for (int j = 0; j < 30; j++) lfg_pow2[0].m[j][j + 1] = 1; /* w'[j] = w[j+1] */
+    lfg_pow2[0].m[30][0] = 1; lfg_pow2[0].m[30][28] = 1;      /* w'[30] = r[n+1] = r[n-30] + r[n-2] = w[0] + w[28] */
+    for (int j = 1; j < 48; j++) lfg_matmul(&lfg_pow2[j - 1], &lfg_pow2[j - 1], &lfg_pow2[j]);
+    lfg_pow2_ready = 1;
+}
+static void lfg_jump(uint32_t *w, uint64_t d) {
+    uint32_t t[31];
+    for (int j = 0; d; j++, d >>= 1)
+        if (d & 1) { lfg_matvec(&lfg_pow2[j], w, t); memcpy(w, t, sizeof t); }
+}
+
+void prach_internal_glibc_seeds(uint32_t seed, uint64_t first, uint64_t nchunks, uint64_t chunk, uint32_t *out /* [nchunks][31] */) {
+    lfg_init_pows();
+    uint32_t r[34];
+    int32_t word = (int32_t)(seed == 0 ? 1u : seed);
+    r[0] = (uint32_t)word;
+    for (int i = 1; i < 31; i++) {
+        int32_t hi = word / 127773, lo = word % 127773;
+        word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        r[i] = (uint32_t)word;
+    }
+    r[31] = r[0]; r[32] = r[1]; r[33] = r[2];
+    uint32_t w[31];
+    for (int j = 0; j < 31; j++) w[j] = r[3 + j];         /* W_33 */
+    lfg_jump(w, 310ull + first);                           /* W_{343+first}: the next value is r[344+first] */
+    lfg_mat step;
+    {   /* A^chunk */
+        lfg_mat acc, tmp;
+        memset(&acc, 0, sizeof acc);
+        for (int i = 0; i < 31; i++) acc.m[i][i] = 1;
+        uint64_t d = chunk;
+        for (int j = 0; d; j++, d >>= 1)
+            if (d & 1) { lfg_matmul(&lfg_pow2[j], &acc, &tmp); acc = tmp; }
+        step = acc;
+    }
+    for (uint64_t c = 0; c < nchunks; c++) {
+        memcpy(out + c * 31, w, sizeof w);
+        uint32_t t[31];
+        lfg_matvec(&step, w, t);
+        memcpy(w, t, sizeof t);
+    }
+}
+
 /* ---- text surfaces ---------------------------------------------------------------------------- */
 
 size_t prach_format_logs(const prach_ue_log *ue, int nUE, char *buf, size_t cap) {

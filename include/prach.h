@@ -122,6 +122,9 @@ int prach_max_time(const prach_cfg *cfg);
 int prach_arrival_schedule(const prach_cfg *cfg, int32_t *out, int cap, int32_t *nAccessUE);
 /* k-th .. k+n-th values of srand(seed)/rand() */
 void prach_glibc_stream(uint32_t seed, uint64_t first, uint64_t n, int32_t *out);
+/* the same stream generated ON THE DEVICE (what glibc-mode trials consume): the host jumps ahead with 31x31 matrix
+ * powers of the lagged-Fibonacci recurrence, one wavefront per 63 488-value chunk rolls it forward */
+int prach_device_glibc_stream(prach_engine *, uint32_t seed, uint64_t first, uint64_t n, int32_t *out);
 const char *prach_strerror(int status);
 
 /* NOMA.c variant (PRACH_VARIANT_NOMA_C): per-UE attributes fixed at activation (activeUE, NOMA.c:131-192):

@@ -320,3 +320,16 @@ def test_legacy_kernel_glibc_mode(pkg, ob, engine):
         engine.set("legacy", 0)
     ores, oues = ob.run_trial(ob.make_cfg(12000, variant=0), ob.Rng(ob.RNG_GLIBC, 6))
     assert_same(pkg, res, logs, ores, oues, "legacy glibc")
+
+
+def test_device_glibc_stream_matches_libc(pkg, engine):
+    """The rand() stream generated on the device (matrix-power jump-ahead + one wavefront per chunk) == libc."""
+    import ctypes as C2
+    libc = C2.CDLL("libc.so.6")
+    for seed, first, n in ((0, 0, 200_000), (7, 123_457, 150_001), (2022, 63_488 * 3 - 5, 70_000)):
+        libc.srand(seed)
+        ref = np.fromiter((libc.rand() for _ in range(first + n)), dtype=np.int64, count=first + n)[first:]
+        dev = engine.device_glibc_stream(seed, first, n).astype(np.int64)
+        assert (dev == ref).all(), (seed, first)
+    big = engine.device_glibc_stream(3, 40_000_000, 1_000_000)
+    assert (big == pkg.glibc_stream(3, 40_000_000, 1_000_000)).all()
