@@ -209,30 +209,46 @@ int main(int argc, char *argv[]) {
         prach_engine_destroy(eng);
         return 0;
     }
-    prach_ue_log *logbuf = want_logs ? (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)sweep_hi) : NULL;
-    for (int randomSeed = 0; randomSeed < randomMax; randomSeed++) { /* WithNOMA:216 */
+    /* glibc mode: within one seed the sweep is chained through the rand() stream (one srand() per seed, WithNOMA:219-221),
+     * but different seeds are independent — so the loop nest is turned inside out: for every nUE point, the trials of ALL
+     * seeds run concurrently in one call, each continuing its own seed's stream.  Output is buffered per seed and
+     * printed in the reference's order. */
+    {
+        uint64_t *offset = (uint64_t *)calloc((size_t)randomMax, sizeof(uint64_t));
+        prach_cfg *cfgs = (prach_cfg *)malloc(sizeof(prach_cfg) * (size_t)randomMax);
+        prach_result *res = (prach_result *)malloc(sizeof(prach_result) * (size_t)randomMax);
+        prach_ue_log **logs = want_logs ? (prach_ue_log **)calloc((size_t)randomMax, sizeof(prach_ue_log *)) : NULL;
+        char **outtxt = (char **)calloc((size_t)randomMax, sizeof(char *));
+        size_t *outlen = (size_t *)calloc((size_t)randomMax, sizeof(size_t));
+        if (!offset || !cfgs || !res || !outtxt || !outlen || (want_logs && !logs)) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+        for (int s_ = 0; s_ < randomMax; s_++) {
+            outtxt[s_] = (char *)malloc((size_t)npts * 1024);
+            if (want_logs) logs[s_] = (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)sweep_hi);
+            if (!outtxt[s_] || (want_logs && !logs[s_])) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+        }
         struct timespec ts0, ts1;
         clock_gettime(CLOCK_MONOTONIC, &ts0);
-        uint64_t offset = 0; /* one srand() per seed; the stream runs on across the sweep (WithNOMA:219-221) */
         for (int k = 0; k < npts; k++) {
-            prach_cfg c = base;
-            c.nUE = sweep_lo + k * sweep_step;
-            c.seed = (uint64_t)randomSeed;
-            c.stream_offset = offset;
-            prach_result r;
-            prach_ue_log *lp = logbuf;
-            rc = prach_run_trials(eng, &c, 1, &r, want_logs ? &lp : NULL);
+            for (int s_ = 0; s_ < randomMax; s_++) {
+                cfgs[s_] = base;
+                cfgs[s_].nUE = sweep_lo + k * sweep_step;
+                cfgs[s_].seed = (uint64_t)s_;
+                cfgs[s_].stream_offset = offset[s_];
+            }
+            rc = prach_run_trials(eng, cfgs, randomMax, res, logs);
             if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-            offset += r.draws;
             clock_gettime(CLOCK_MONOTONIC, &ts1);
             const double lat = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
-            prach_format_stdout(&c, &r, lat, text, sizeof text);
-            fputs(text, stdout);
-            rc = prach_write_trial_files(&c, &r, want_logs ? logbuf : NULL, lat, outdir);
-            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+            for (int s_ = 0; s_ < randomMax; s_++) {
+                offset[s_] += res[s_].draws;
+                outlen[s_] += prach_format_stdout(&cfgs[s_], &res[s_], lat, outtxt[s_] + outlen[s_], 1024);
+                rc = prach_write_trial_files(&cfgs[s_], &res[s_], want_logs ? logs[s_] : NULL, lat, outdir);
+                if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+            }
         }
+        for (int s_ = 0; s_ < randomMax; s_++) { fwrite(outtxt[s_], 1, outlen[s_], stdout); free(outtxt[s_]); if (want_logs) free(logs[s_]); }
+        free(offset); free(cfgs); free(res); free(logs); free(outtxt); free(outlen);
     }
-    free(logbuf);
     prach_engine_destroy(eng);
     return 0;
 }

@@ -333,3 +333,22 @@ def test_device_glibc_stream_matches_libc(pkg, engine):
         assert (dev == ref).all(), (seed, first)
     big = engine.device_glibc_stream(3, 40_000_000, 1_000_000)
     assert (big == pkg.glibc_stream(3, 40_000_000, 1_000_000)).all()
+
+
+def test_cli_multi_seed_glibc_matches_reference(pkg, engine, tmp_path):
+    """`prach_sim -d 0 -p 30 -b 40 -g 20 -rc 3 -mrc 20 -t 3`: the reference's 3-seed run (golden noma_seed2), first two
+    sweep points of every seed — stdout in the reference's order, Results.txt and Logs.txt byte-identical.  Internally
+    the seeds of one sweep point run concurrently, each on its own chained rand() stream."""
+    g = load_golden("noma_seed2")
+    p = subprocess.run([pkg.CLI_PATH] + g["argv"] + ["--sweep", "10000:20000:10000", "--out", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    blocks = split_stdout_blocks(g["stdout"])
+    exp_blocks = []
+    for k, tr in enumerate(g["trials"]):
+        if tr["nUE"] <= 20000:
+            exp_blocks.append(blocks[k])
+            d = tmp_path / tr["dir"]
+            assert (d / tr["results_file"]).read_text() == tr["results_text"], (tr["seed"], tr["nUE"])
+            assert hashlib.sha256((d / tr["logs_file"]).read_bytes()).hexdigest() == tr["logs_sha256"], (tr["seed"], tr["nUE"])
+    assert split_stdout_blocks(p.stdout) == exp_blocks and len(exp_blocks) == 6
