@@ -37,10 +37,10 @@ hbm = (2.0 * fetch + write) * 1024.0
 traffic = {"tag": tag, "kernel": main["Name"], "avg_kernel_ns": float(main["AverageNs"]), "calls": int(main["Calls"]),
            "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write, "fetch_correction": 2.0,
            "hbm_bytes_per_launch": hbm,
-           "method": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extras`"}
+           "method": "separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras`"}
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 with open(os.path.join(out, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary {tag}\n\ncommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-extras`\n\n")
+    f.write(f"# rocprofv3 summary {tag}\n\ncommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras`\n\n")
     f.write("| kernel | calls | avg ms | % |\n|---|---|---|---|\n")
     for r in rows:
         f.write(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {r['Percentage']} |\n")
