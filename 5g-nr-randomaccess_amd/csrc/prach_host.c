@@ -61,7 +61,7 @@ const char *prach_strerror(int s) {
     switch (s) {
     case PRACH_OK: return "ok";
     case PRACH_ERR_ARG: return "invalid argument";
-    case PRACH_ERR_UNSUPPORTED: return "parameter outside the supported range (nPreamble<=254, maxRarWindow<=255, maxMsg2TxCount<=255)";
+    case PRACH_ERR_UNSUPPORTED: return "parameter outside the supported range (nPreamble<=254, maxRarWindow<=255, maxMsg2TxCount<=255, nUE<=2^24; NOMA_C: nPreamble<=64, Philox draws, Beta arrivals)";
     case PRACH_ERR_DEVICE: return "HIP device/runtime error (an MI355X/gfx950 device is required; there is no CPU fallback)";
     case PRACH_ERR_STREAM: return "glibc draw stream exhausted";
     case PRACH_ERR_INTERNAL: return "device-side consistency check failed";

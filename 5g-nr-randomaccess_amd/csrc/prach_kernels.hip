@@ -380,9 +380,8 @@ __device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const i
     // reset cycles that could land on this subframe: strictly in index order (rare, few)
     const int nrc = L.scal[S_NRC];
     if (nrc > 0) {
-        if (tid == 0) {
-            if (nrc > RCCAP) L.scal[S_STATUS] = PRACH_ERR_INTERNAL;
-            const int n = min(nrc, RCCAP);
+        if (tid == 0 && nrc <= RCCAP) {
+            const int n = nrc;
             for (int a = 1; a < n; a++) { // insertion sort: list position == index order
                 const int v = L.rclist[a];
                 int b = a - 1;
@@ -393,6 +392,16 @@ __device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const i
                 Event e = EVA[L.rclist[a]];
                 const int p = (e.info >> 8) & 0xff, q = (e.info >> 16) & 0xff;
                 if (L.fcall[q] < e.idx) { e.info = 0; EVA[L.rclist[a]] = e; } // bumped before its turn
+                else if (e.idx < L.fcall[p]) L.fcall[p] = e.idx;
+            }
+        } else if (tid == 0) {
+            // more candidates than the staged list holds (degenerate parameters: every expiry is a reset cycle):
+            // the event list itself is in index order, walk it — slow, exact, any size
+            for (int k = 0; k < N; k++) {
+                Event e = EVA[k];
+                if ((e.info & 0xff) != EV_RESETCAND) continue;
+                const int p = (e.info >> 8) & 0xff, q = (e.info >> 16) & 0xff;
+                if (L.fcall[q] < e.idx) { e.info = 0; EVA[k] = e; }
                 else if (e.idx < L.fcall[p]) L.fcall[p] = e.idx;
             }
         }

@@ -32,7 +32,7 @@ namespace {
 
 // packed word of the NOMA record
 constexpr unsigned N_RA_BIT = 1u << 2, N_FAIL_BIT = 1u << 3, N_MSG2_BIT = 1u << 4, N_M3W_BIT = 1u << 5, N_PRE_SHIFT = 6,
-                   N_RETX_SHIFT = 14;
+                   N_RETX_SHIFT = 14, N_RAR5_BIT = 1u << 22;
 constexpr int NOMA_VARIANT = 2;
 constexpr unsigned NGR_NONE = 0xFFFFFu;
 constexpr unsigned NSPIN_LIMIT = 1u << 22;
@@ -117,6 +117,9 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
 
     int activeCheck = 0, time_exit = P.stop, status = PRACH_OK;
     bool all_done = false;
+    // msg2Results SETS rarWindow to the literal 5 and then compares it with maxRarWindow (NOMA.c:453-455): with
+    // maxRarWindow > 5 a failed transmitter is never rescheduled (txTime += 3 and rarWindow = 5 is all that happens)
+    const bool rar_expires = 5 >= P.maxRarWindow;
 
     for (int s = 0, t0 = 0; t0 < P.stop && status == PRACH_OK; s++, t0 += aT) {
         const int t = t0; // the slot's subframe (time % accessTime == 0)
@@ -285,9 +288,9 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     const bool granted = tx && (pk & PK_GRANT_BIT);
                     const bool txfail = tx && !granted && !(pk & N_MSG2_BIT);
                     int retx = (int)((pk >> N_RETX_SHIFT) & 0xff);
-                    const bool perm = txfail && retx + 1 >= P.maxMsg2; // msg1ReTx reaches maxMsg1ReTx: dropped for good
+                    const bool perm = txfail && rar_expires && retx + 1 >= P.maxMsg2; // msg1ReTx reaches maxMsg1ReTx: dropped for good
                     int d1 = 0, d2 = 0;
-                    if (__any(txfail)) {
+                    if (rar_expires && __any(txfail)) {
                         if (txfail) { k = P.nd[i]; nd_loaded = true; }
                         d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, NOMA_VARIANT);
                         if (__any(perm)) d2 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, NOMA_VARIANT);
@@ -296,6 +299,10 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     if (granted) { // NOMA.c:491-497
                         pk = (pk & ~(3u | N_M3W_BIT | PK_GRANT_BIT)) | 2u | N_MSG2_BIT;
                         r.x += 10; P.stt[i] = r.x;
+                        dirty = true;
+                    } else if (txfail && !rar_expires) { // NOMA.c:452-455 with the window test false
+                        r.x += 3;
+                        pk |= N_RAR5_BIT;
                         dirty = true;
                     } else if (txfail) { // NOMA.c:452-489
                         r.x += 3;
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         r.x = slot_align_fm(r.x + tmp, fmA);
                         P.stt[i] = r.x;
                         r.z = enc_backoff(r.x - tt - 1, tt);
-                        pk = (pk & ~(3u | N_MSG2_BIT | (0xffu << N_PRE_SHIFT) | (0xffu << N_RETX_SHIFT))) | 1u | ((unsigned)np << N_PRE_SHIFT);
+                        pk = (pk & ~(3u | N_MSG2_BIT | N_RAR5_BIT | (0xffu << N_PRE_SHIFT) | (0xffu << N_RETX_SHIFT))) | 1u | ((unsigned)np << N_PRE_SHIFT);
                         P.ptc[i] = 0;
                         r.y = tt;
                         dirty = true;
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             o.nowBackoff = (ra || fail) ? r.z : now_backoff(r.z, tend);
             o.preamble = (int)((pk >> N_PRE_SHIFT) & 0xff);
             o.preambleChange = i < activeCheck ? sector[i] : -1;         // NOMA: sector
-            o.rarWindow = 0;
+            o.rarWindow = (pk & N_RAR5_BIT) ? 5 : 0;                      // NOMA.c:453 / :457,485,539
             o.maxRarCounter = (int)((pk >> N_RETX_SHIFT) & 0xff);        // NOMA: msg1ReTx
             o.preambleTxCounter = ntx;                                    // NOMA: nTxPreamble
             o.msg2Flag = (pk & N_MSG2_BIT) ? 1 : 0;                       // NOMA: msg2

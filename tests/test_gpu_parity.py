@@ -42,6 +42,9 @@ ORACLE_CASES = [
     (1, 9000, dict(nPreamble=64, backoff=10, nGrantUL=8, maxRarWindow=5, maxMsg2TxCount=4, accessTime=10)),
     (0, 9000, dict(nPreamble=254, backoff=7, nGrantUL=200, maxRarWindow=255, maxMsg2TxCount=255)),
     (0, 1, {}), (1, 63, {}), (0, 64, {}), (1, 65, {}), (0, 1025, {}),  # ragged sizes around wave / workgroup width
+    # reset storm: every expiry is a reset cycle and nobody is ever granted -> more re-join candidates per subframe than the
+    # cluster kernel stages (falls back to the single-workgroup kernel, which walks them in index order)
+    (1, 2600, dict(uniform=1, nPreamble=54, backoff=5, nGrantUL=1, maxRarWindow=1, maxMsg2TxCount=0, accessTime=10)),
 ]
 
 
@@ -352,3 +355,41 @@ def test_cli_multi_seed_glibc_matches_reference(pkg, engine, tmp_path):
             assert (d / tr["results_file"]).read_text() == tr["results_text"], (tr["seed"], tr["nUE"])
             assert hashlib.sha256((d / tr["logs_file"]).read_bytes()).hexdigest() == tr["logs_sha256"], (tr["seed"], tr["nUE"])
     assert split_stdout_blocks(p.stdout) == exp_blocks and len(exp_blocks) == 6
+
+
+def _random_cases(n, seed):
+    """Seeded random corners of the parameter space the CLI accepts (Beta.c:463-516 / WithNOMA:433-545):
+    tiny and odd preamble counts, accessTime != 5 (the hard-coded 5 of Beta.c:112,389 then matters),
+    grant budgets of 0 (nGrantUL=1) to plenty, immediate retransmission limits, both arrival laws."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for k in range(n):
+        nUE = int(rs.choice([1, 2, 63, 64, 65, 130, 700, 1500, 2600, 4100, 6000]))
+        kw = dict(nPreamble=int(rs.choice([1, 2, 3, 7, 16, 54, 64, 97, 200])),
+                  backoff=int(rs.choice([1, 2, 5, 20, 33, 60])),
+                  nGrantUL=int(rs.choice([1, 2, 3, 6, 12, 54, 300])),
+                  maxRarWindow=int(rs.choice([1, 2, 3, 6, 11])),
+                  maxMsg2TxCount=int(rs.choice([0, 1, 2, 9, 30])),
+                  accessTime=int(rs.choice([1, 2, 5, 6, 10, 16])),
+                  uniform=int(rs.rand() < 0.3))
+        if kw["uniform"]:
+            nUE = min(nUE, 2600)  # 60 000 subframes: keep the oracle in seconds
+        out.append((int(rs.randint(0, 2)), nUE, kw, int(rs.randint(0, 2)), int(rs.randint(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("G", [0, 3])
+def test_random_parameter_sweep(pkg, ob, engine, G):
+    """96 random configurations in ONE call (concurrent trials, mixed RNG modes / variants / sizes), every
+    counter and every logged field of every UE against the oracle; once with the engine's own
+    cluster size and once forced to 3 workgroups per trial (uneven ownership)."""
+    cases = _random_cases(96, 20240 + G)
+    engine.set("cluster", G)
+    try:
+        cfgs = [pkg.make_cfg(n, variant=v, rng_mode=r, seed=s, **kw) for (v, n, kw, r, s) in cases]
+        res, logs = engine.run_trials(cfgs, want_logs=True)
+    finally:
+        engine.set("cluster", 0)
+    for (v, n, kw, r, s), rb, lb in zip(cases, res, logs):
+        ores, oues = ob.run_trial(ob.make_cfg(n, variant=v, **kw), ob.Rng(r, s))
+        assert_same(pkg, rb, lb, ores, oues, (v, n, kw, r, s, G))

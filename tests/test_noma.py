@@ -53,7 +53,9 @@ def test_noma_activation_table_matches_oracle(pkg, ob):
 
 
 NOMA_GPU_CASES = [(3000, 0, {}), (10000, 1, {}), (30000, 2, {}), (64, 3, {}), (1, 4, {}), (5000, 5, dict(nPreamble=8, backoff=3)),
-                  (8000, 6, dict(nGrantUL=1, maxMsg2TxCount=3)), (8000, 7, dict(nPreamble=64, nGrantUL=5, backoff=40))]
+                  (8000, 6, dict(nGrantUL=1, maxMsg2TxCount=3)), (8000, 7, dict(nPreamble=64, nGrantUL=5, backoff=40)),
+                  # maxRarWindow > 5: NOMA.c:453-455 sets rarWindow to the literal 5 before the test, so nobody is rescheduled
+                  (8000, 8, dict(maxRarWindow=6)), (6000, 9, dict(maxRarWindow=7, accessTime=3, nGrantUL=3))]
 
 
 @pytest.mark.gpu
@@ -112,3 +114,30 @@ def test_gpu_noma_cluster_sizes(pkg, ob, engine, G):
             assert (a == b).all(), (G, nUE)
     finally:
         engine.set("cluster", 0)
+
+
+@pytest.mark.gpu
+def test_gpu_noma_random_parameter_sweep(pkg, ob, engine):
+    """48 seeded random configurations of NOMA.c's constants (NOMA.c:41-57) in ONE call (concurrent trials):
+    aggregates and every logged field of every UE against the oracle."""
+    rs = np.random.RandomState(77)
+    cases = []
+    for _ in range(48):
+        kw = dict(nPreamble=int(rs.choice([1, 2, 3, 8, 33, 54, 64])), backoff=int(rs.randint(1, 60)), nGrantUL=int(rs.choice([1, 2, 3, 5, 12, 40])),
+                  maxRarWindow=int(rs.randint(1, 10)), maxMsg2TxCount=int(rs.choice([0, 1, 3, 10, 25])), accessTime=int(rs.choice([1, 2, 3, 5, 5, 8, 10])))
+        if rs.rand() < 0.3:
+            kw["max_steps"] = int(rs.randint(1, 6000))
+        if rs.rand() < 0.3:
+            kw["cellRadius"] = float(rs.choice([50.0, 250.0, 2000.0]))
+        cases.append((int(rs.choice([1, 7, 64, 65, 500, 2000, 6000, 12000])), int(rs.randint(0, 1 << 30)), kw))
+    cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=s, **kw) for n, s, kw in cases]
+    res, logs = engine.run_trials(cfgs, want_logs=True)
+    for (n, s, kw), r, lg in zip(cases, res, logs):
+        okw = dict(kw)
+        okw["maxMsg1ReTx"] = okw.pop("maxMsg2TxCount")
+        ores, oues = ob.noma_run_trial(ob.make_noma_cfg(n, **okw), ob.Rng(ob.RNG_PHILOX, s))
+        assert (r.status, r.nSuccessUE, r.sumTimer, r.preambleTxCount, r.failCounts, r.activeCheck, r.draws, r.time_exit) == \
+               (0, ores.nSuccessUE, ores.delay, ores.nTxP, ores.raFailedUEs, ores.activeCheck, ores.draws, ores.time_exit), (n, s, kw)
+        a = np.frombuffer(lg, dtype=np.int32).reshape(-1, 16)
+        b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
+        assert (a == b).all(), (n, s, kw)
