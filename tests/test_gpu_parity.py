@@ -393,3 +393,29 @@ def test_random_parameter_sweep(pkg, ob, engine, G):
     for (v, n, kw, r, s), rb, lb in zip(cases, res, logs):
         ores, oues = ob.run_trial(ob.make_cfg(n, variant=v, **kw), ob.Rng(r, s))
         assert_same(pkg, rb, lb, ores, oues, (v, n, kw, r, s, G))
+
+
+def test_gpu_reproduces_reference_random_flags(pkg, engine):
+    """The product path against the REAL reference under 63 random flag sets (tests/golden/ref_fuzz.json, made by
+    tests/golden/fuzz_reference.py): every finished sweep point's Results.txt bytes, printed block and per-UE
+    Logs.txt SHA-256, the rand() stream carried across the sweep through cfg.stream_offset — no oracle involved."""
+    import json
+    fz = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fuzz.json")))
+    checked = 0
+    for r in fz["runs"]:
+        off = 0
+        for k, tr in enumerate(r["trials"]):
+            cfg = pkg.make_cfg(tr["nUE"], variant=1, rng_mode=pkg.RNG_GLIBC, seed=0, stream_offset=off, **r["cfg_overrides"])
+            (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+            what = (r["argv"], tr["nUE"])
+            assert res.status == 0, what
+            off += res.draws
+            assert pkg.format_results(cfg, res, 0.0).decode() == tr["results_text"], what
+            so = pkg.format_stdout(cfg, res, 0.0).decode()
+            so = "".join(l + "\n" for l in so.split("\n") if l and not l.startswith("Latency:"))
+            assert so == r["stdout_blocks"][k], what
+            text = pkg.format_logs(logs, tr["nUE"])
+            assert len(text) == tr["logs_bytes"], what
+            assert hashlib.sha256(text).hexdigest() == tr["logs_sha256"], what
+            checked += 1
+    assert checked >= 170

@@ -66,3 +66,35 @@ def test_reference_published_statistics(ob):
     cfg = ob.make_cfg(30000, variant=ob.VARIANT_WITHNOMA_C)
     res, _ = ob.run_trial(cfg, ob.Rng(ob.RNG_GLIBC, 0), want_ues=False)
     assert abs(100.0 * res.nSuccessUE / 30000 - 60.913) < 1.5
+
+
+def load_ref_fuzz():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fuzz.json")))
+
+
+def test_oracle_reproduces_reference_random_flags(ob):
+    """63 random flag sets (-d -p -b -g -rc -mrc -s) of the REAL RandomAccessWithNOMA, the sweep points it
+    finished in its time budget (tests/golden/fuzz_reference.py): Results.txt bytes, printed block and the
+    SHA-256 of the per-UE Logs.txt of every point, with the rand() stream carried across the sweep.
+    The default run checks the first sweep point of every Beta run and of every third Uniform run (60 000
+    subframes each), so the CPU suite stays at a few minutes; PRACH_FULL_GOLDEN=1 checks all 175 trials (all
+    verified that way), and the GPU suite checks all of them against the product path."""
+    fz = load_ref_fuzz()
+    assert len(fz["runs"]) >= 60
+    checked = 0
+    for r in fz["runs"]:
+        rng = ob.Rng(ob.RNG_GLIBC, 0)
+        for k, tr in enumerate(r["trials"]):
+            if not FULL and (k > 0 or (r["cfg_overrides"]["uniform"] and r["run"] % 3 != 0)):
+                break
+            cfg = ob.make_cfg(tr["nUE"], variant=ob.VARIANT_WITHNOMA_C, **r["cfg_overrides"])
+            res, ues = ob.run_trial(cfg, rng)
+            what = (r["argv"], tr["nUE"])
+            assert ob.format_results(cfg, res).decode() == tr["results_text"], what
+            assert ob.format_stdout(cfg, res).decode() == r["stdout_blocks"][k], what
+            logs = ob.format_logs(ues, cfg.nUE)
+            assert len(logs) == tr["logs_bytes"], what
+            assert hashlib.sha256(logs).hexdigest() == tr["logs_sha256"], what
+            checked += 1
+    assert checked >= 45
