@@ -141,3 +141,26 @@ def test_gpu_noma_random_parameter_sweep(pkg, ob, engine):
         a = np.frombuffer(lg, dtype=np.int32).reshape(-1, 16)
         b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
         assert (a == b).all(), (n, s, kw)
+
+
+def test_noma_oracle_reproduces_reference_random_parameters(ob):
+    """48 random settings of NOMA.c's file-scope parameters (NOMA.c:41-57; set by oracle/noma_params_main.c in front
+    of the reference's own main, tests/golden/fuzz_reference_noma.py): the lines the REAL program printed for the
+    sweep points it finished, glibc stream chained over the sweep.  Default: the first point of every run
+    (PRACH_FULL_GOLDEN=1: all 192 lines; all verified that way)."""
+    import json
+    import os
+    fz = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fuzz_noma.json")))
+    full = os.environ.get("PRACH_FULL_GOLDEN") == "1"
+    assert len(fz["runs"]) >= 45
+    checked = 0
+    for r in fz["runs"]:
+        rng = ob.Rng(ob.RNG_GLIBC, 0)
+        for k, line in enumerate(r["lines"] if full else r["lines"][:1]):
+            n = 10000 * (k + 1)
+            assert int(line.split()[0]) == n
+            cfg = ob.make_noma_cfg(n, **r["cfg_overrides"])
+            res, _ = ob.noma_run_trial(cfg, rng, want_ues=False)
+            assert ob.noma_format_line(cfg, res).decode().strip() == line, (r["argv"], n)
+            checked += 1
+    assert checked >= 45
