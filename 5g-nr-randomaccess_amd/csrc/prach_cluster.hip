@@ -149,35 +149,39 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
     const int tmod = t % aT;
     const FastMod fmP = FM.nP, fmB = FM.backoff, fmA = FM.aT, fm5 = FM.five;
 
-    // software pipeline: the next live group's record (and Philox draw index) is in flight while the
-    // current group is processed (state is L2-resident; the pass is latency-, not bandwidth-bound)
+    // software pipeline: the next live groups' records (and Philox draw indices) are in flight while the
+    // current group is processed
     auto next_live = [&](int jj) -> int {
         for (;; jj += NW) {
             if (C.b + C.G * jj >= ngroups) return -1;
             if (!((L.dead[(jj >> 5) & (DEADW - 1)] >> (jj & 31)) & 1u)) return jj;
         }
     };
-    int jn = next_live(w);
-    int4 rn = make_int4(-1, 0, 0, 0);
-    unsigned ndn = 0;
-    if (jn >= 0) {
-        const int in = (C.b + C.G * jn) * 64 + lane;
-        if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (MODE == 0) ndn = P.nd[in]; }
-    }
-    while (jn >= 0) {
-        const int j = jn;
+    // two groups ahead (slots A, B): in the batched regime the records stream from HBM (three ahead measured slower)
+    auto fetch = [&](int jj, int4 &rr, unsigned &nn) {
+        rr = make_int4(-1, 0, 0, 0);
+        nn = 0;
+        if (jj >= 0) {
+            const int in = (C.b + C.G * jj) * 64 + lane;
+            if (in < activeCheck) { rr = load_rec(&P.rec[in]); if (MODE == 0) nn = P.nd[in]; }
+        }
+    };
+    int jA = next_live(w), jB;
+    int4 rA, rB;
+    unsigned ndA, ndB;
+    fetch(jA, rA, ndA);
+    jB = jA >= 0 ? next_live(jA + NW) : -1;
+    fetch(jB, rB, ndB);
+    while (jA >= 0) {
+        const int j = jA;
         const int g = C.b + C.G * j;
         const int i = g * 64 + lane;
         const bool valid = i < activeCheck;
-        const int4 r = rn;
-        unsigned ndc = ndn;
-        jn = next_live(j + NW);
-        rn = make_int4(-1, 0, 0, 0);
-        ndn = 0;
-        if (jn >= 0) {
-            const int in = (C.b + C.G * jn) * 64 + lane;
-            if (in < activeCheck) { rn = load_rec(&P.rec[in]); if (MODE == 0) ndn = P.nd[in]; }
-        }
+        const int4 r = rA;
+        unsigned ndc = ndA;
+        jA = jB; rA = rB; ndA = ndB;
+        jB = jA >= 0 ? next_live(jA + NW) : -1;
+        fetch(jB, rB, ndB);
         bool nd_dirty = false;
         UeState u = unpack(r);
         bool dirty = false;

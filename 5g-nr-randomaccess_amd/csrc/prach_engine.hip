@@ -368,6 +368,12 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
         for (int k = 0; k < n; k++)
             if (cfgs[k].rng_mode == mode && cfgs[k].variant != PRACH_VARIANT_NOMA_C) idx.push_back(k);
         if (idx.empty()) continue;
+        // longest trials first: workgroups are dispatched in index order as CUs free up, so the tail of a
+        // many-trial launch is made of the short trials
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+            auto work = [&](int k) { return (uint64_t)cfgs[k].nUE * (uint64_t)(cfgs[k].max_steps > 0 ? cfgs[k].max_steps : prach_max_time(&cfgs[k])); };
+            return work(a) > work(b);
+        });
         bool cluster_ok = !e->opt_legacy;
         for (int k : idx) {
             cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
