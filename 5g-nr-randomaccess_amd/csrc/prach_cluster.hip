@@ -49,7 +49,7 @@ constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups)
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 enum { C_NSUCC = 0, C_COLL, C_TXOP, C_CONTF, C_NS, C_NRC, C_NRJ, C_STATUS, C_NEV, C_NCAND, C_OVF, C_NSUCCTOT, C_NTOT,
-       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20, C_GTOT = 21 };
+       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20, C_GTOT = 21, C_QN = 22, C_QEND = 23 };
 
 struct CLds {
     int2 *gev;    // [EVCAPC] gathered events of all workgroups
@@ -61,10 +61,12 @@ struct CLds {
     int *bins;    // [GBINS] grant selection: singleton callers per index bin (then exclusive prefix)
     int *wtot;    // [NW]
     int *hist, *mloc, *total, *fcall, *lcall, *nlv, *fie; // [nP] each
+    int *queue;   // [QCAP] Philox pass: UEs of this workgroup that have an event in this subframe
     int *gsum;    // [GSCAP] glibc mode: rand() calls of every 64-UE group in this subframe's UE loop
     int *gpre;    // [GSCAP] their exclusive prefix in index order
 };
 constexpr int GBINS = 1024;
+constexpr int QCAP = 8192;  // event queue of the compacted pass (more: the overflowing wavefront works in place)
 constexpr int GSCAP = 4096; // glibc mode on the cluster kernel: at most 4096 groups (262 144 UEs)
 constexpr int MAXG = 64; // the gather's header phase is one wavefront: lane = workgroup
 
@@ -81,16 +83,15 @@ __device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc) {
     L.wtot = ip; ip += NW;
     L.hist = ip; ip += nP; L.mloc = ip; ip += nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
     L.lcall = ip; ip += 2 * nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
+    L.queue = ip; ip += QCAP;
     L.gsum = ip; L.gpre = ip + GSCAP; // only carved (and only touched) in glibc mode
     (void)glibc;
     return L;
 }
 
 // shared words: every access is a device-scope relaxed atomic == global_load/store ... sc1
-__device__ __forceinline__ int ld_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ long long ld_sc1_64(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1_64(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld_sc1_64(const PRACH_G long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1_64(PRACH_G long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct FastMods { FastMod nP, backoff, aT, five; };
 
@@ -108,7 +109,7 @@ __device__ __forceinline__ bool granule_ok(long long g, unsigned tag) {
     return (w0 >> 20) == (tag & 0xFFFu) && ((w1 >> 20) & 0xFu) == ((tag >> 12) & 0xFu);
 }
 // bounded re-read of one granule until it carries `tag`
-__device__ __forceinline__ long long wait_granule(const long long *p, unsigned tag, int *status_word) {
+__device__ __forceinline__ long long wait_granule(const PRACH_G long long *p, unsigned tag, int *status_word) {
     long long g = ld_sc1_64(p);
     unsigned spins = 0;
     while (!granule_ok(g, tag)) {
@@ -121,238 +122,251 @@ __device__ __forceinline__ long long wait_granule(const long long *p, unsigned t
 
 struct Ctx {
     int b, G, evw, mbstride;
-    int *mbox;      // [2][G][mbstride ints]: per workgroup 1 header + nP bucket + evw event granules
-    unsigned *bar;  // monotonic arrival counter of this trial
-    int2 *cand;     // this workgroup's private early-leaver candidate scratch
+    PRACH_G int *mbox;   // [2][G][mbstride ints]: per workgroup 1 header + nP bucket + evw event granules
+    PRACH_G v2i_t *cand; // this workgroup's private early-leaver candidate scratch
 };
 
-__device__ __forceinline__ long long *gr_of(const Ctx &C, int parity, int wg) {
-    return reinterpret_cast<long long *>(C.mbox + ((size_t)parity * C.G + wg) * C.mbstride);
+__device__ __forceinline__ PRACH_G long long *gr_of(const Ctx &C, int parity, int wg) {
+    return reinterpret_cast<PRACH_G long long *>(C.mbox + ((size_t)parity * C.G + wg) * C.mbstride);
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass over the groups this workgroup owns.  MODE 0: fused apply + activate + select (Philox);
-// glibc mode splits it: MODE 1 apply + activate + per-group draw counts, MODE 2 select with stream offsets;
+// One subframe of the UE loop for the 64 UEs a wavefront holds (lane = UE; the UEs need not be neighbours).
+// MODE 0: fused apply + activate + select (Philox); glibc mode splits it: MODE 1 apply + activate + per-group
+// draw counts, MODE 2 select with stream offsets (both need the lanes to be one 64-UE group in index order);
 // MODE 3: only the deferred apply of the last subframe.
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall, const int *lcall,
-                                             const int t, const int prevAC,
-                                             const int activeCheck, long long *mbev, const unsigned tag, const unsigned long long stepbase) {
+__device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall, const int *lcall,
+                                        const int t, const int prevAC, PRACH_G long long *mbev, const unsigned tag, const unsigned long long stepbase,
+                                        const int lane, const int g, const int jdead, const int i, const bool valid, const int4 r, unsigned ndc,
+                                        int &c_succ, int &c_contf) {
     constexpr bool FINAL = MODE == 3;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int aT = P.aT, nUE = P.nUE;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
-    const int ngroups = (activeCheck + 63) >> 6;
     const int tp = t - 1;
-    int c_succ = 0, c_contf = 0;
     const int tmod = t % aT;
     const FastMod fmP = FM.nP, fmB = FM.backoff, fmA = FM.aT, fm5 = FM.five;
+    bool nd_dirty = false;
+    UeState u = unpack(r);
+    bool dirty = false;
+
+    // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
+    if (MODE != 2 && u.pend != PEND_NONE) {
+        if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
+            u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
+            if (u.pend == PEND_RESET) u.bo = 0;
+        } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
+            u.tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
+        } else if (u.pend == PEND_RESET) {
+            const int q = u.bo, tmp = u.tx;
+            const int bumped = fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
+            const int x = slot_align_fm(tp + bumped + tmp, fmA);
+            if (x == tp) { u.bo = 0; u.tx = tp + 1; }
+            else { u.tx = x; u.bo = x; }
+        } else if (u.pend == PEND_PASSIVE) {
+            if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
+        } else { // PEND_RJOIN
+            if (lcall[u.pre - 1] > i) u.tx = tp + 1;
+        }
+        u.pend = PEND_NONE;
+        dirty = true;
+    }
+    if (FINAL) {
+        if (dirty) store_rec(&P.rec[i], pack(u));
+        return;
+    }
+    // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
+    if (MODE != 2 && valid && i >= prevAC) {
+        u.act = ACT_M1; u.tx = t + 1; u.tb = t;
+        P.ftt[i] = t + 1;
+        if (MODE == 0 && withnoma) { ndc = 2; nd_dirty = true; }
+        dirty = true;
+    }
+
+    const bool isM1 = u.act == ACT_M1;
+    const int nb = now_backoff(u.bo, t);
+    const bool firstsel = isM1 && u.pre == 0;
+    const bool contend = isM1 && u.pre != 0 && nb <= 0;
+    const bool expire = contend && (u.rar + 1 >= P.maxRarWindow);
+    const bool reset = expire && u.mrc >= P.maxMsg2;
+    const bool retx = expire && !reset;
+    const bool m3due = u.act == ACT_M3 && u.tx == t;
+    const bool m3first = m3due && u.conn == 0, m3to = m3due && u.conn != 0;
+    const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
+    const bool busy = isM1 || m3due;
+
+    if (MODE == 1) { // glibc: this group's rand() calls in the UE loop of subframe t (own pre-step state only)
+        const int gs = __popcll(__ballot(need >= 1)) + __popcll(__ballot(need == 2));
+        if (lane == 0) L.gsum[g] = gs;
+        if (dirty) store_rec(&P.rec[i], pack(u));
+        return;
+    }
+
+    if (!__any(busy || dirty)) {
+        // nothing happens in this group; retire it for good once every UE in it has finished
+        if (jdead >= 0 && __all(i >= nUE || u.act == ACT_DONE) && lane == 0) atomicOr(&L.dead[(jdead >> 5) & (DEADW - 1)], 1u << (jdead & 31));
+        return;
+    }
+
+    int d1 = 0, d2 = 0;
+    if (MODE == 2) { // the reference's own stream: position = draws before this subframe's UE loop + index-ordered prefix
+        if (__any(need > 0)) {
+            int x = need;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            const unsigned long long o = stepbase + (unsigned long long)L.gpre[g] + (unsigned long long)(x - need);
+            if (need > 0) d1 = P.stream[o];
+            if (need > 1) d2 = P.stream[o + 1];
+        }
+    } else if (__any(need > 0)) {
+        const unsigned k = ndc;
+        d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, (unsigned)P.variant);
+        if (__any(need > 1))
+            d2 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, (unsigned)P.variant);
+        if (need > 0) { ndc = k + (unsigned)need; nd_dirty = true; }
+    }
+
+    // ---- selectPreamble / requestResourceAllocation on own state ----
+    const int oldp = u.pre - 1;
+    const bool member_pre = isM1 && u.tx == t && u.pre != 0; // matched by a preambleCollision scan right now
+    int evtype = 0, evp = 0, evq = 0;
+    bool eclass = false; // pre-member that leaves its bucket at its own turn without calling on it
+    if (firstsel) { // Beta.c:231-239
+        u.pre = fastmod(d1, fmP) + 1; u.rar = 0; u.mrc = 0; u.bo = 0;
+        P.ptc[i] = 1;
+        if (withnoma) P.fcnt[i] = 0;
+        if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = u.pre - 1; }
+        dirty = true;
+    } else if (isM1 && u.pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
+        if (member_pre) { u.pend = withnoma ? PEND_STAY : PEND_PASSIVE; dirty = true; } // WithNOMA:310 calls anyway
+    } else if (contend) {
+        u.rar++; // Beta.c:245
+        dirty = true;
+        if (reset) { // Beta.c:250-281
+            if (withnoma) { c_contf++; P.fcnt[i] = P.fcnt[i] + 1; }
+            const int newp = fastmod(d1, fmP);
+            const int tmp = fastmod(d2, fmB);
+            u.rar = 0; u.mrc = 0; u.tb = t;
+            P.ptc[i] = 1; P.ftt[i] = t + 1;
+            u.pre = newp + 1;
+            if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
+                u.pend = PEND_RESET; u.tx = tmp; u.bo = oldp;
+                eclass = true;
+                if (tmp == 0 && aT > 1 && tmod == 1) { evtype = EVC_RESETCAND; evp = newp; evq = oldp; }
+            } else {
+                u.tx = slot_align_fm(u.tx + tmp, fmA);
+                u.bo = enc_backoff(u.tx - t, t);
+                if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = newp; }
+            }
+        } else if (retx) { // Beta.c:282-308
+            u.rar = 0; u.mrc++;
+            P.ptc[i] = P.ptc[i] + 1;
+            const int tmp = fastmod(d1, fmB);
+            u.tx = slot_align_fm(t + tmp, fmA);
+            u.bo = enc_backoff(u.tx - t, t);
+            P.stt[i] = u.tx;
+            if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = oldp; } // the "late joiner"
+            else if (member_pre) eclass = true;
+        } else if (member_pre) {
+            u.pend = PEND_STAY;
+        }
+    } else if (m3first) { // Beta.c:372-383
+        u.conn = 1;
+        const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
+        if ((double)pf > 0.1) { u.act = ACT_DONE; u.tb = (t - u.tb) + 6; c_succ++; }
+        else { u.conn = 2; u.tx += 48; }
+        dirty = true;
+    } else if (m3to) { // Msg3 timeout, Beta.c:384-410
+        c_contf++;
+        const int tmp = fastmod(d1, fmB);
+        u.tx = slot_align_fm(u.tx + tmp, fm5); // hard-coded accessTime = 5, Beta.c:389
+        u.act = ACT_M1;
+        u.bo = enc_backoff(u.tx - t, t);
+        u.pre = fastmod(d2, fmP) + 1;
+        u.tb = t; u.rar = 0; u.mrc = 0; u.conn = 0;
+        if (withnoma) P.fcnt[i] = P.fcnt[i] + 1;
+        if (u.tx == t) { u.pend = PEND_RJOIN; evtype = EVC_RJOIN; evp = u.pre - 1; }
+        dirty = true;
+    }
+
+    // ---- bucket bookkeeping (workgroup-level LDS atomics) ----
+    if (member_pre) atomicAdd(&L.hist[oldp], 1);
+    if (u.pend == PEND_STAY) { if (__atomic_load_n(&L.mloc[oldp], __ATOMIC_RELAXED) > i) atomicMin(&L.mloc[oldp], i); }
+    if (evtype == EVC_CALLER) atomicMin(&L.mloc[evp], i);
+    {
+        const unsigned long long em = __ballot(evtype != 0);
+        if (em) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&L.scal[C_NEV], __popcll(em));
+            base = __shfl(base, 0);
+            if (evtype != 0) {
+                const int slot = base + __popcll(em & lanemask_lt(lane));
+                const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
+                const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
+                if (C.G == 1) { if (slot < EVCAPC) L.gev[slot] = make_int2(i, info); }
+                else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)i, (unsigned)info, tag));
+            }
+        }
+        const unsigned long long cm = __ballot(eclass);
+        if (cm) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&L.scal[C_NCAND], __popcll(cm));
+            base = __shfl(base, 0);
+            if (eclass) store_i2(&C.cand[base + __popcll(cm & lanemask_lt(lane))], i, oldp);
+        }
+    }
+    if (nd_dirty) P.nd[i] = ndc;
+    if (dirty) store_rec(&P.rec[i], pack(u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense pass over the groups this workgroup owns (glibc modes, the final apply)
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall, const int *lcall,
+                                             const int t, const int prevAC,
+                                             const int activeCheck, PRACH_G long long *mbev, const unsigned tag, const unsigned long long stepbase) {
+    constexpr bool FINAL = MODE == 3;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = (activeCheck + 63) >> 6;
+    int c_succ = 0, c_contf = 0;
 
     // software pipeline: the next live groups' records (and Philox draw indices) are in flight while the
     // current group is processed
-    auto next_live = [&](int jj) -> int {
+    auto next_live = [&](int jj) -> int { // wave-uniform: group indices live in scalar registers
         for (;; jj += NW) {
             if (C.b + C.G * jj >= ngroups) return -1;
-            if (!((L.dead[(jj >> 5) & (DEADW - 1)] >> (jj & 31)) & 1u)) return jj;
+            const unsigned word = __builtin_amdgcn_readfirstlane(L.dead[(jj >> 5) & (DEADW - 1)]);
+            if (!((word >> (jj & 31)) & 1u)) return jj;
         }
     };
-    // two groups ahead (slots A, B): in the batched regime the records stream from HBM (three ahead measured slower)
-    auto fetch = [&](int jj, int4 &rr, unsigned &nn) {
-        rr = make_int4(-1, 0, 0, 0);
-        nn = 0;
-        if (jj >= 0) {
-            const int in = (C.b + C.G * jj) * 64 + lane;
-            if (in < activeCheck) { rr = load_rec(&P.rec[in]); if (MODE == 0) nn = P.nd[in]; }
-        }
+    // two groups ahead (slots A, B; three ahead measured slower).  The load itself is unconditional (record 0 is always
+    // mapped) and the "nothing there" case is applied where the record is consumed: a conditional load would have to be
+    // waited for on the spot to merge it with the default value, which serialises the prefetches.
+    auto fetch = [&](int jj, int4 &rr, unsigned &nn, bool &ok) {
+        const int in = (C.b + C.G * max(jj, 0)) * 64 + lane;
+        ok = jj >= 0 && in < activeCheck;
+        rr = load_rec(&P.rec[ok ? in : 0]);
+        nn = MODE == 0 ? P.nd[ok ? in : 0] : 0u;
     };
     int jA = next_live(w), jB;
     int4 rA, rB;
     unsigned ndA, ndB;
-    fetch(jA, rA, ndA);
+    bool okA, okB;
+    fetch(jA, rA, ndA, okA);
     jB = jA >= 0 ? next_live(jA + NW) : -1;
-    fetch(jB, rB, ndB);
+    fetch(jB, rB, ndB, okB);
     while (jA >= 0) {
         const int j = jA;
         const int g = C.b + C.G * j;
         const int i = g * 64 + lane;
-        const bool valid = i < activeCheck;
-        const int4 r = rA;
-        unsigned ndc = ndA;
-        jA = jB; rA = rB; ndA = ndB;
+        const int4 r = okA ? rA : make_int4(-1, 0, 0, 0);
+        const unsigned ndc = okA ? ndA : 0u;
+        jA = jB; rA = rB; ndA = ndB; okA = okB;
         jB = jA >= 0 ? next_live(jA + NW) : -1;
-        fetch(jB, rB, ndB);
-        bool nd_dirty = false;
-        UeState u = unpack(r);
-        bool dirty = false;
-
-        // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
-        if (MODE != 2 && u.pend != PEND_NONE) {
-            if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
-                u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
-                if (u.pend == PEND_RESET) u.bo = 0;
-            } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
-                u.tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
-            } else if (u.pend == PEND_RESET) {
-                const int q = u.bo, tmp = u.tx;
-                const int bumped = fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
-                const int x = slot_align_fm(tp + bumped + tmp, fmA);
-                if (x == tp) { u.bo = 0; u.tx = tp + 1; }
-                else { u.tx = x; u.bo = x; }
-            } else if (u.pend == PEND_PASSIVE) {
-                if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
-            } else { // PEND_RJOIN
-                if (lcall[u.pre - 1] > i) u.tx = tp + 1;
-            }
-            u.pend = PEND_NONE;
-            dirty = true;
-        }
-        if (FINAL) {
-            if (dirty) P.rec[i] = pack(u);
-            continue;
-        }
-        // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
-        if (MODE != 2 && valid && i >= prevAC) {
-            u.act = ACT_M1; u.tx = t + 1; u.tb = t;
-            P.ftt[i] = t + 1;
-            if (MODE == 0 && withnoma) { ndc = 2; nd_dirty = true; }
-            dirty = true;
-        }
-
-        const bool isM1 = u.act == ACT_M1;
-        const int nb = now_backoff(u.bo, t);
-        const bool firstsel = isM1 && u.pre == 0;
-        const bool contend = isM1 && u.pre != 0 && nb <= 0;
-        const bool expire = contend && (u.rar + 1 >= P.maxRarWindow);
-        const bool reset = expire && u.mrc >= P.maxMsg2;
-        const bool retx = expire && !reset;
-        const bool m3due = u.act == ACT_M3 && u.tx == t;
-        const bool m3first = m3due && u.conn == 0, m3to = m3due && u.conn != 0;
-        const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
-        const bool busy = isM1 || m3due;
-
-        if (MODE == 1) { // glibc: this group's rand() calls in the UE loop of subframe t (own pre-step state only)
-            const int gs = __popcll(__ballot(need >= 1)) + __popcll(__ballot(need == 2));
-            if (lane == 0) L.gsum[g] = gs;
-            if (dirty) P.rec[i] = pack(u);
-            continue;
-        }
-
-        if (!__any(busy || dirty)) {
-            // nothing happens in this group; retire it for good once every UE in it has finished
-            if (__all(i >= nUE || u.act == ACT_DONE) && lane == 0) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
-            continue;
-        }
-
-        int d1 = 0, d2 = 0;
-        if (MODE == 2) { // the reference's own stream: position = draws before this subframe's UE loop + index-ordered prefix
-            if (__any(need > 0)) {
-                int x = need;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
-                const unsigned long long o = stepbase + (unsigned long long)L.gpre[g] + (unsigned long long)(x - need);
-                if (need > 0) d1 = P.stream[o];
-                if (need > 1) d2 = P.stream[o + 1];
-            }
-        } else if (__any(need > 0)) {
-            const unsigned k = ndc;
-            d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, (unsigned)P.variant);
-            if (__any(need > 1))
-                d2 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, (unsigned)P.variant);
-            if (need > 0) { ndc = k + (unsigned)need; nd_dirty = true; }
-        }
-
-        // ---- selectPreamble / requestResourceAllocation on own state ----
-        const int oldp = u.pre - 1;
-        const bool member_pre = isM1 && u.tx == t && u.pre != 0; // matched by a preambleCollision scan right now
-        int evtype = 0, evp = 0, evq = 0;
-        bool eclass = false; // pre-member that leaves its bucket at its own turn without calling on it
-        if (firstsel) { // Beta.c:231-239
-            u.pre = fastmod(d1, fmP) + 1; u.rar = 0; u.mrc = 0; u.bo = 0;
-            P.ptc[i] = 1;
-            if (withnoma) P.fcnt[i] = 0;
-            if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = u.pre - 1; }
-            dirty = true;
-        } else if (isM1 && u.pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
-            if (member_pre) { u.pend = withnoma ? PEND_STAY : PEND_PASSIVE; dirty = true; } // WithNOMA:310 calls anyway
-        } else if (contend) {
-            u.rar++; // Beta.c:245
-            dirty = true;
-            if (reset) { // Beta.c:250-281
-                if (withnoma) { c_contf++; P.fcnt[i] = P.fcnt[i] + 1; }
-                const int newp = fastmod(d1, fmP);
-                const int tmp = fastmod(d2, fmB);
-                u.rar = 0; u.mrc = 0; u.tb = t;
-                P.ptc[i] = 1; P.ftt[i] = t + 1;
-                u.pre = newp + 1;
-                if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
-                    u.pend = PEND_RESET; u.tx = tmp; u.bo = oldp;
-                    eclass = true;
-                    if (tmp == 0 && aT > 1 && tmod == 1) { evtype = EVC_RESETCAND; evp = newp; evq = oldp; }
-                } else {
-                    u.tx = slot_align_fm(u.tx + tmp, fmA);
-                    u.bo = enc_backoff(u.tx - t, t);
-                    if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = newp; }
-                }
-            } else if (retx) { // Beta.c:282-308
-                u.rar = 0; u.mrc++;
-                P.ptc[i] = P.ptc[i] + 1;
-                const int tmp = fastmod(d1, fmB);
-                u.tx = slot_align_fm(t + tmp, fmA);
-                u.bo = enc_backoff(u.tx - t, t);
-                P.stt[i] = u.tx;
-                if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = oldp; } // the "late joiner"
-                else if (member_pre) eclass = true;
-            } else if (member_pre) {
-                u.pend = PEND_STAY;
-            }
-        } else if (m3first) { // Beta.c:372-383
-            u.conn = 1;
-            const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
-            if ((double)pf > 0.1) { u.act = ACT_DONE; u.tb = (t - u.tb) + 6; c_succ++; }
-            else { u.conn = 2; u.tx += 48; }
-            dirty = true;
-        } else if (m3to) { // Msg3 timeout, Beta.c:384-410
-            c_contf++;
-            const int tmp = fastmod(d1, fmB);
-            u.tx = slot_align_fm(u.tx + tmp, fm5); // hard-coded accessTime = 5, Beta.c:389
-            u.act = ACT_M1;
-            u.bo = enc_backoff(u.tx - t, t);
-            u.pre = fastmod(d2, fmP) + 1;
-            u.tb = t; u.rar = 0; u.mrc = 0; u.conn = 0;
-            if (withnoma) P.fcnt[i] = P.fcnt[i] + 1;
-            if (u.tx == t) { u.pend = PEND_RJOIN; evtype = EVC_RJOIN; evp = u.pre - 1; }
-            dirty = true;
-        }
-
-        // ---- bucket bookkeeping (workgroup-level LDS atomics) ----
-        if (member_pre) atomicAdd(&L.hist[oldp], 1);
-        if (u.pend == PEND_STAY) { if (__atomic_load_n(&L.mloc[oldp], __ATOMIC_RELAXED) > i) atomicMin(&L.mloc[oldp], i); }
-        if (evtype == EVC_CALLER) atomicMin(&L.mloc[evp], i);
-        {
-            const unsigned long long em = __ballot(evtype != 0);
-            if (em) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&L.scal[C_NEV], __popcll(em));
-                base = __shfl(base, 0);
-                if (evtype != 0) {
-                    const int slot = base + __popcll(em & lanemask_lt(lane));
-                    const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
-                    const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
-                    if (C.G == 1) { if (slot < EVCAPC) L.gev[slot] = make_int2(i, info); }
-                    else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)i, (unsigned)info, tag));
-                }
-            }
-            const unsigned long long cm = __ballot(eclass);
-            if (cm) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&L.scal[C_NCAND], __popcll(cm));
-                base = __shfl(base, 0);
-                if (eclass) C.cand[base + __popcll(cm & lanemask_lt(lane))] = make_int2(i, oldp);
-            }
-        }
-        if (nd_dirty) P.nd[i] = ndc;
-        if (dirty) P.rec[i] = pack(u);
+        fetch(jB, rB, ndB, okB);
+        ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, g, j, i, i < activeCheck, r, ndc, c_succ, c_contf);
     }
     if (!FINAL) {
 #pragma unroll
@@ -361,6 +375,126 @@ __device__ __forceinline__ void cluster_pass(const TrialDev &P, const CLds &L, c
             if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
             if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox pass, compacted.  In a 64-UE group nearly every subframe SOME UE has an event (a draw, an expiry, a
+// deferred outcome), so the dense pass executes every branch of ue_step for every group at a few per cent lane
+// utilisation — and the pass is instruction-issue bound (rocprofv3: >90 % issue-busy).  Here phase A walks the
+// groups with a short straight-line body that handles the two cheap, overwhelmingly common cases in place —
+// nothing to do, and the steady contention cycle "bumped last subframe, RAR window still open" (Beta.c:245 plus the
+// txTime++ of Beta.c:346,358: rarWindow++, stay matched, count into the bucket) — and queues every other UE; phase B
+// runs ue_step on the queued UEs 64 at a time, all lanes busy.  ue_step never looks at a lane's neighbours in MODE 0,
+// so the result is the same whichever wavefront a UE lands in.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall,
+                                                     const int *lcall, const int t, const int prevAC, const int activeCheck, PRACH_G long long *mbev,
+                                                     const unsigned tag
+#ifdef PRACH_STAMPS
+                                                     , unsigned long long *stamps, unsigned long long &tprev
+#endif
+                                                     ) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroups = (activeCheck + 63) >> 6;
+    const int nUE = P.nUE, maxRar = P.maxRarWindow;
+    int c_succ = 0, c_contf = 0;
+    auto next_live = [&](int jj) -> int { // wave-uniform: group indices live in scalar registers
+        for (;; jj += NW) {
+            if (C.b + C.G * jj >= ngroups) return -1;
+            const unsigned word = __builtin_amdgcn_readfirstlane(L.dead[(jj >> 5) & (DEADW - 1)]);
+            if (!((word >> (jj & 31)) & 1u)) return jj;
+        }
+    };
+    auto fetch = [&](int jj, int4 &rr, bool &ok) { // unconditional load, see cluster_pass
+        const int in = (C.b + C.G * max(jj, 0)) * 64 + lane;
+        ok = jj >= 0 && in < activeCheck;
+        rr = load_rec(&P.rec[ok ? in : 0]);
+    };
+    // ---- phase A ----  (records PFD groups ahead; 4 measured no faster batched, slower for a single trial)
+    constexpr int PFD = 2;
+    int jq[PFD];
+    int4 rq[PFD];
+    bool okq[PFD];
+    jq[0] = next_live(w);
+    fetch(jq[0], rq[0], okq[0]);
+#pragma unroll
+    for (int d = 1; d < PFD; d++) {
+        jq[d] = jq[d - 1] >= 0 ? next_live(jq[d - 1] + NW) : -1;
+        fetch(jq[d], rq[d], okq[d]);
+    }
+    while (jq[0] >= 0) {
+        const int j = jq[0];
+        const int g = C.b + C.G * j;
+        const int i = g * 64 + lane;
+        const int4 r = okq[0] ? rq[0] : make_int4(-1, 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d + 1 < PFD; d++) { jq[d] = jq[d + 1]; rq[d] = rq[d + 1]; okq[d] = okq[d + 1]; }
+        jq[PFD - 1] = jq[PFD - 2] >= 0 ? next_live(jq[PFD - 2] + NW) : -1;
+        fetch(jq[PFD - 1], rq[PFD - 1], okq[PFD - 1]);
+
+        const bool valid = i < activeCheck;
+        const unsigned pk = (unsigned)r.w;
+        const int act = (int)(pk >> PK_ACT_SHIFT) & 3, pre = (int)(pk >> PK_PRE_SHIFT) & 0xff, rar = (int)(pk >> PK_RAR_SHIFT) & 0xff,
+                  pend = (int)(pk >> PK_PEND_SHIFT) & 7;
+        const bool old = valid && i < prevAC;
+        const bool plainbump = (unsigned)(pend - 1) < 2u && !(pk & PK_GRANT_BIT); // PEND_STAY / PEND_CALLER without a grant: txTime++
+        const int tx = plainbump ? t : r.x;
+        const bool isM1 = act == ACT_M1;
+        const bool contend = isM1 && pre != 0 && now_backoff(r.z, t) <= 0;
+        const bool lightc = old && (pend == PEND_NONE || plainbump) && contend && rar + 1 < maxRar;
+        const bool quiet = !valid || (old && pend == PEND_NONE && !contend && !(isM1 && pre == 0) && !((isM1 || act == ACT_M3) && r.x == t));
+        const bool heavy = !lightc && !quiet;
+        if (!__any(lightc || heavy)) {
+            // nothing happens in this group; retire it for good once every UE in it has finished
+            if (__all(i >= nUE || act == ACT_DONE) && lane == 0) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
+            continue;
+        }
+        if (lightc) {
+            const bool member = tx == t;
+            const unsigned npk = (pk & ~((0xffu << PK_RAR_SHIFT) | (7u << PK_PEND_SHIFT) | PK_GRANT_BIT)) | ((unsigned)(rar + 1) << PK_RAR_SHIFT) |
+                                 (member ? (unsigned)PEND_STAY << PK_PEND_SHIFT : 0u);
+            store_rec(&P.rec[i], make_int4(tx, r.y, r.z, (int)npk));
+            if (member) {
+                atomicAdd(&L.hist[pre - 1], 1);
+                if (__atomic_load_n(&L.mloc[pre - 1], __ATOMIC_RELAXED) > i) atomicMin(&L.mloc[pre - 1], i);
+            }
+        }
+        const unsigned long long hm = __ballot(heavy);
+        if (hm) {
+            const int n = __popcll(hm);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&L.scal[C_QN], n);
+            base = __shfl(base, 0);
+            if (base + n <= QCAP) {
+                if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = i;
+            } else { // queue full: this wavefront does its events in place
+                if (lane == 0) atomicMin(&L.scal[C_QEND], base);
+                unsigned ndc = 0;
+                if (heavy) ndc = P.nd[i];
+                ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, g, -1, i, heavy, heavy ? r : make_int4(-1, 0, 0, 0), ndc,
+                           c_succ, c_contf);
+            }
+        }
+    }
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+    // ---- phase B ----
+    const int qn = min(L.scal[C_QN], L.scal[C_QEND]);
+    for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
+        const bool v = q0 + lane < qn;
+        const int i = v ? L.queue[q0 + lane] : 0;
+        int4 r = make_int4(-1, 0, 0, 0);
+        unsigned ndc = 0;
+        if (v) { r = load_rec(&P.rec[i]); ndc = P.nd[i]; }
+        ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, i >> 6, -1, i, v, r, ndc, c_succ, c_contf);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+    if (lane == 0) {
+        if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
+        if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
     }
 }
 
@@ -441,7 +575,7 @@ template <bool GLIBC>
 __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = blockIdx.x % nT, b = blockIdx.x / nT;
-    const TrialDev P = params[T];
+    const TrialG P(params[T]);
     const CLds L = ccarve(smem, P.nP, GLIBC);
     const int tid = threadIdx.x;
     const int nUE = P.nUE, nP = P.nP, aT = P.aT;
@@ -450,7 +584,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     FastMods FM;
     FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
     Ctx C;
-    C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox; C.bar = P.bar;
+    C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox;
     const int totgroups = (nUE + 63) >> 6;
     const int lgroups = (totgroups + G - 1) / G; // local groups of any workgroup (upper bound)
     C.cand = P.cand + (size_t)b * lgroups * 64;
@@ -459,7 +593,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
         if (g < totgroups && i < nUE) {
-            P.rec[i] = make_int4(-1, 0, 0, 0);
+            store_rec(&P.rec[i], make_int4(-1, 0, 0, 0));
             P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0; P.nd[i] = 0;
         }
     }
@@ -467,7 +601,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.fcall[nP + k] = INT_MAX; L.lcall[nP + k] = -1;
         L.nlv[k] = 0; L.fie[k] = 0;
     }
-    if (tid < 64) L.scal[tid] = 0;
+    if (tid < 64) L.scal[tid] = tid == C_QEND ? QCAP : 0;
     for (int k = tid; k < DEADW; k += WG_THREADS) L.dead[k] = 0;
     if (GLIBC) for (int k = tid; k < GSCAP; k += WG_THREADS) { L.gsum[k] = 0; L.gpre[k] = 0; }
     __syncthreads();
@@ -489,8 +623,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         if (t % aT == 0 && activeCheck != nUE) activeCheck = P.sched[t / aT]; // Beta.c:121-134
         const int parity = t & 1;
         const unsigned tag = (unsigned)(t + 1);
-        long long *const mygr = G > 1 ? gr_of(C, parity, b) : nullptr;
-        long long *const mbev = G > 1 ? mygr + 1 + nP : nullptr;
+        PRACH_G long long *const mygr = G > 1 ? gr_of(C, parity, b) : nullptr;
+        PRACH_G long long *const mbev = G > 1 ? mygr + 1 + nP : nullptr;
         // first / last caller tables are double-buffered by subframe parity: this subframe's resolver fills [A],
         // the pass (apply of the previous subframe) reads [B]
         int *const fcallA = L.fcall + parity * nP, *const lcallA = L.lcall + parity * nP;
@@ -506,7 +640,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             __syncthreads();
             if (G > 1) {
                 const int nq = (lgroups + 1) >> 1;
-                long long *const mine = mygr + 1 + nP + C.evw;
+                PRACH_G long long *const mine = mygr + 1 + nP + C.evw;
                 for (int q = tid; q < nq; q += WG_THREADS) {
                     const int g0 = b + G * (2 * q), g1 = b + G * (2 * q + 1);
                     st_sc1_64(mine + q, mk_granule(g0 < totgroups ? (unsigned)L.gsum[g0] : 0u, g1 < totgroups ? (unsigned)L.gsum[g1] : 0u, tag));
@@ -544,7 +678,12 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             cluster_pass<2>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, base + actdraws);
             base += tot;
         } else {
-            cluster_pass<0>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+            if (P.dense_pass) cluster_pass<0>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+            else cluster_pass_compact(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag
+#ifdef PRACH_STAMPS
+                                      , stamps, tprev
+#endif
+                                      );
         }
         __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
         STAMP(0);
@@ -552,7 +691,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         // early leavers below this workgroup's lowest caller are the only ones a rank can need
         const int ncand = L.scal[C_NCAND];
         for (int k = tid; k < ncand; k += WG_THREADS) {
-            const int2 c = C.cand[k];
+            const v2i_t c = C.cand[k];
             if (c.x < L.mloc[c.y]) {
                 const int slot = atomicAdd(&L.scal[C_NEV], 1);
                 const int info = EVC_LEAVER | (c.y << 4);
@@ -574,7 +713,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             if (nevraw > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
             N = nevraw;
             __syncthreads(); // S3
-            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NSUCCTOT] = L.scal[C_NSUCC]; }
+            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NSUCCTOT] = L.scal[C_NSUCC]; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP; }
             STAMP(1); STAMP(2);
             // classify the events: reset-cycle candidates, Msg3 re-entries, early leavers below / callers at the first call
             for (int k = tid; k < N; k += WG_THREADS) classify_event(L, fcallA, k, L.gev[k]);
@@ -589,7 +728,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             if (tid == 0) {
                 const int nevraw = L.scal[C_NEV];
                 st_sc1_64(mygr, mk_granule((unsigned)min(nevraw, C.evw) | (nevraw > C.evw ? (1u << 13) : 0u), (unsigned)L.scal[C_NSUCC], tag));
-                L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0;
+                L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP;
             }
             STAMP(1);
             // round 1: the bucket granules of every workgroup (all threads) and, on the last wavefront, the headers
@@ -733,7 +872,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 const int before = L.bins[bin];
                 if (before >= Gr) continue;
                 const int cnt = (bin + 1 < GBINS ? L.bins[bin + 1] : ns) - before;
-                if (before + cnt <= Gr) { if (((my >> 6) % G) == b) atomicOr(reinterpret_cast<unsigned *>(&P.rec[my]) + 3, PK_GRANT_BIT); }
+                if (before + cnt <= Gr) { if (((my >> 6) % G) == b) grant_rec(&P.rec[my]); }
                 else { const int s_ = atomicAdd(&L.scal[C_NCROSS], 1); if (s_ < RCCAP) L.rclist[s_] = my; }
             }
             __syncthreads();
@@ -743,7 +882,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 const int my = L.rclist[tid];
                 int rank = L.bins[my >> binshift];
                 for (int m = 0; m < ncross; m++) rank += L.rclist[m] < my ? 1 : 0;
-                if (rank < Gr && ((my >> 6) % G) == b) atomicOr(reinterpret_cast<unsigned *>(&P.rec[my]) + 3, PK_GRANT_BIT);
+                if (rank < Gr && ((my >> 6) % G) == b) grant_rec(&P.rec[my]);
             }
         }
         grantCheck += ns;
@@ -768,7 +907,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
         if (g >= totgroups || i >= nUE) continue;
-        const UeState u = unpack(P.rec[i]);
+        const UeState u = unpack(load_rec_plain(&P.rec[i]));
         const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
         const int ptc = P.ptc[i], fc = P.fcnt[i];
         if (u.act == ACT_DONE) { sumT += timer; ptcS += ptc; fcS += fc; }
@@ -781,7 +920,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             o.preambleChange = u.pre != 0; o.rarWindow = u.rar; o.maxRarCounter = u.mrc; o.preambleTxCounter = ptc;
             o.msg2Flag = (u.act == ACT_M3 || u.act == ACT_DONE); o.connectionRequest = u.conn == 2 ? 48 : u.conn;
             o.msg4Flag = u.act == ACT_DONE; o.failCount = fc;
-            P.logs[i] = o;
+            store_log(P.logs, i, o);
         }
     }
 #pragma unroll
@@ -796,16 +935,16 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     }
     __syncthreads();
     if (tid == 0) { // DevResult was zeroed by the engine before the launch
-        DevResult *o = P.out;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&o->sumTimer), *reinterpret_cast<unsigned long long *>(&L.scal[C_SUMT]));
-        if (GLIBC) { if (b == 0) atomicAdd(&o->draws, base); }
-        else atomicAdd(&o->draws, *reinterpret_cast<unsigned long long *>(&L.scal[C_ND]));
-        atomicAdd(&o->ptcSum, L.scal[C_PTC]);
-        atomicAdd(&o->fcSum, L.scal[C_FC]);
-        atomicAdd(&o->nSuccess, L.scal[C_NSUCC]);
-        atomicAdd(&o->finalSuccess, L.scal[C_NSUCC]);
-        atomicAdd(&o->continueFailed, L.scal[C_CONTF]);
-        if (status != PRACH_OK) atomicMin(&o->status, status);
+        PRACH_G DevResult *o = P.out;
+        gadd(&o->sumTimer, *reinterpret_cast<long long *>(&L.scal[C_SUMT]));
+        if (GLIBC) { if (b == 0) gadd(&o->draws, base); }
+        else gadd(&o->draws, *reinterpret_cast<unsigned long long *>(&L.scal[C_ND]));
+        gadd(&o->ptcSum, L.scal[C_PTC]);
+        gadd(&o->fcSum, L.scal[C_FC]);
+        gadd(&o->nSuccess, L.scal[C_NSUCC]);
+        gadd(&o->finalSuccess, L.scal[C_NSUCC]);
+        gadd(&o->continueFailed, L.scal[C_CONTF]);
+        if (status != PRACH_OK) gmin(&o->status, status);
         if (b == 0) {
 #ifdef PRACH_STAMPS
             for (int k = 0; k < 8; k++) o->stamps6[k] = stamps[k];
@@ -821,7 +960,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 }
 
 size_t cluster_kernel_lds_bytes(int nP, bool glibc) {
-    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 9 * nP + (glibc ? 2 * GSCAP : 0));
+    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 9 * nP + QCAP + (glibc ? 2 * GSCAP : 0));
 }
 
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, hipStream_t stream) {

@@ -52,13 +52,90 @@ __device__ __forceinline__ unsigned long long lanemask_le(int lane) {
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 
+// ---------------------------------------------------------------------------------------------
+// Device memory is addressed in the GLOBAL address space, explicitly.  The per-trial pointers reach a kernel
+// inside a parameter block loaded from memory, which the compiler can only treat as generic pointers: every
+// access becomes a flat_* instruction (64-bit address arithmetic per lane, and it counts on lgkmcnt as well as
+// vmcnt, so each LDS wait also drains the outstanding record loads — a software prefetch cannot overlap
+// anything).  TrialG is the same block with address_space(1) pointers: global_load/store/atomic with a scalar
+// base, and the record prefetch really stays in flight.
+// ---------------------------------------------------------------------------------------------
+#define PRACH_G __attribute__((address_space(1)))
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+static_assert(sizeof(prach_ue_log) == 64 && sizeof(Event) == 16, "records are stored as 16-byte vectors");
+
+struct TrialG {
+    int variant, uniform, nUE, nP, backoff, nGrantUL, maxRarWindow, maxMsg2, aT, rng_mode, maxTime, stop;
+    unsigned seed_lo, seed_hi;
+    unsigned long long stream_len;
+    PRACH_G v4i_t *rec;
+    PRACH_G int *ptc, *ftt, *stt, *fcnt;
+    PRACH_G unsigned *nd;
+    PRACH_G v4i_t *evbuf, *evbuf2; // Event records
+    PRACH_G int *sidx;
+    const PRACH_G int *sched;
+    const PRACH_G int *stream;
+    PRACH_G v4i_t *logs; // prach_ue_log = four 16-byte vectors; null: no per-UE log wanted
+    PRACH_G int *timers;
+    PRACH_G DevResult *out;
+    int evw, mbstride, binshift;
+    PRACH_G int *mbox;
+    PRACH_G unsigned *bar;
+    PRACH_G v2i_t *cand;
+    int dense_pass;
+    const PRACH_G int *n_pre0, *n_sector;
+    const PRACH_G double *n_gain, *n_lgain;
+    const PRACH_G unsigned *n_nd0;
+
+    __device__ __forceinline__ explicit TrialG(const TrialDev &d)
+        : variant(d.variant), uniform(d.uniform), nUE(d.nUE), nP(d.nP), backoff(d.backoff), nGrantUL(d.nGrantUL), maxRarWindow(d.maxRarWindow),
+          maxMsg2(d.maxMsg2), aT(d.aT), rng_mode(d.rng_mode), maxTime(d.maxTime), stop(d.stop), seed_lo(d.seed_lo), seed_hi(d.seed_hi),
+          stream_len(d.stream_len), rec((PRACH_G v4i_t *)d.rec), ptc((PRACH_G int *)d.ptc), ftt((PRACH_G int *)d.ftt), stt((PRACH_G int *)d.stt),
+          fcnt((PRACH_G int *)d.fcnt), nd((PRACH_G unsigned *)d.nd), evbuf((PRACH_G v4i_t *)d.evbuf), evbuf2((PRACH_G v4i_t *)d.evbuf2),
+          sidx((PRACH_G int *)d.sidx), sched((const PRACH_G int *)d.sched), stream((const PRACH_G int *)d.stream), logs((PRACH_G v4i_t *)d.logs),
+          timers((PRACH_G int *)d.timers), out((PRACH_G DevResult *)d.out), evw(d.evw), mbstride(d.mbstride), binshift(d.binshift),
+          mbox((PRACH_G int *)d.mbox), bar((PRACH_G unsigned *)d.bar), cand((PRACH_G v2i_t *)d.cand), dense_pass(d.dense_pass),
+          n_pre0((const PRACH_G int *)d.n_pre0), n_sector((const PRACH_G int *)d.n_sector), n_gain((const PRACH_G double *)d.n_gain),
+          n_lgain((const PRACH_G double *)d.n_lgain), n_nd0((const PRACH_G unsigned *)d.n_nd0) {}
+};
+
 // The hot record is read with a non-temporal 16-byte load (global_load_dwordx4 ... nt: served by L2, never
 // by this CU's L1): the resolver sets the grant bit with an L2 atomic, which a stale L1 line would hide.
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int4 load_rec(const int4 *p) {
-    const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t *>(p));
+__device__ __forceinline__ int4 load_rec(const PRACH_G v4i_t *p) {
+    const v4i_t v = __builtin_nontemporal_load(p);
     return make_int4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ int4 load_rec_plain(const PRACH_G v4i_t *p) {
+    const v4i_t v = *p;
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_rec(PRACH_G v4i_t *p, const int4 r) {
+    v4i_t v;
+    v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w;
+    *p = v;
+}
+__device__ __forceinline__ void grant_rec(PRACH_G v4i_t *p) { // one fire-and-forget L2 atomic on the packed word
+    __hip_atomic_fetch_or(reinterpret_cast<PRACH_G unsigned *>(p) + 3, PK_GRANT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_i2(PRACH_G v2i_t *p, const int a, const int b) {
+    v2i_t v;
+    v.x = a; v.y = b;
+    *p = v;
+}
+__device__ __forceinline__ void store_log(PRACH_G v4i_t *logs, const int i, const prach_ue_log &o) {
+    const int *w = reinterpret_cast<const int *>(&o);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v4i_t v;
+        v.x = w[4 * k]; v.y = w[4 * k + 1]; v.z = w[4 * k + 2]; v.w = w[4 * k + 3];
+        logs[(size_t)i * 4 + k] = v;
+    }
+}
+// agent-scope relaxed read-modify-writes on global memory (results of a trial)
+template <class T> __device__ __forceinline__ void gadd(PRACH_G T *p, const T v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void gmin(PRACH_G T *p, const T v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void gmax(PRACH_G T *p, const T v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // decode / encode of the packed word of the hot record (prach_device.h)
 struct UeState {

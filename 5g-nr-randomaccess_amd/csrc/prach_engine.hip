@@ -35,6 +35,7 @@ struct prach_engine {
     int64_t opt_stream_factor = 0; // glibc: initial draws-per-UE budget override (0 = auto)
     int64_t opt_cluster = 0;       // workgroups per trial for the Philox cluster kernel (0 = auto)
     int64_t opt_legacy = 0;        // 1: run Philox trials on the one-workgroup trial_kernel as well
+    int64_t opt_dense = 0;         // 1: cluster kernel without the compacted pass (diagnostic)
     int last_G = 0;
     int num_cus = 256;            // co-residency budget of the cluster kernels: one 1024-thread workgroup per CU
 };
@@ -139,6 +140,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "stream_factor") == 0) { e->opt_stream_factor = value; return PRACH_OK; }
     if (std::strcmp(key, "cluster") == 0) { if (value < 0 || value > CLUSTER_MAX_G) return PRACH_ERR_ARG; e->opt_cluster = value; return PRACH_OK; }
     if (std::strcmp(key, "legacy") == 0) { e->opt_legacy = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "dense") == 0) { e->opt_dense = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }
 
@@ -207,6 +209,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.stop = (c.max_steps > 0 && c.max_steps < d.maxTime) ? c.max_steps : d.maxTime;
         d.seed_lo = (unsigned)c.seed; d.seed_hi = (unsigned)(c.seed >> 32);
         d.stream_len = L.stream_len;
+        d.dense_pass = e->opt_dense ? 1 : 0;
         char *A = e->arena;
         d.rec = reinterpret_cast<int4 *>(A + L.rec);
         d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);

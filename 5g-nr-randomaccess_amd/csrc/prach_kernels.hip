@@ -82,7 +82,7 @@ size_t trial_kernel_lds_bytes(int nP) {
 //                                                3 apply only                         [final]
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool GLIBC>
-__device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const int t, const int prevAC,
+__device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int t, const int prevAC,
                                         const int activeCheck, const unsigned long long stepbase) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nP = P.nP, aT = P.aT;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
                 r.x = tx; r.y = tb; r.z = bo;
                 r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
                       (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
-                P.rec[i] = r;
+                store_rec(&P.rec[i], r);
             }
             continue;
         }
@@ -170,7 +170,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
                 r.x = tx; r.y = tb; r.z = bo;
                 r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
                       (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
-                P.rec[i] = r;
+                store_rec(&P.rec[i], r);
             }
             continue;
         }
@@ -303,7 +303,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
                 if (evtype != 0) {
                     Event e;
                     e.idx = i; e.info = evtype | (evp << 8) | (evq << 16); e.le = le; e.pad = 0;
-                    P.evbuf[g0 * 64 + evn + __popcll(em & lanemask_lt(lane))] = e;
+                    ((Event *)P.evbuf)[g0 * 64 + evn + __popcll(em & lanemask_lt(lane))] = e;
                 }
                 evn += __popcll(em);
             }
@@ -312,7 +312,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
             r.x = tx; r.y = tb; r.z = bo;
             r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
                   (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
-            P.rec[i] = r;
+            store_rec(&P.rec[i], r);
         }
     }
 
@@ -335,7 +335,7 @@ __device__ __forceinline__ void ue_pass(const TrialDev &P, const Lds &L, const i
 // ---------------------------------------------------------------------------------------------
 // resolve subframe t: who calls preambleCollision, with what scan count, who gets the RAR grants
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const int activeCheck, int &grantCheck) {
+__device__ __forceinline__ void resolve(const TrialG &P, const Lds &L, const int activeCheck, int &grantCheck) {
     const int tid = threadIdx.x;
     const int nP = P.nP;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
@@ -363,11 +363,11 @@ __device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const i
     __syncthreads();
 
     const int N = L.evoff[NW];
-    Event *const EVA = N <= EVCAP ? L.evl : P.evbuf2;
+    Event *const EVA = N <= EVCAP ? L.evl : (Event *)P.evbuf2; // LDS or global: a generic pointer
     for (int k = tid; k < N; k += WG_THREADS) {
         int w = 0;
         while (w + 1 < NW && L.evoff[w + 1] <= k) w++;
-        Event e = P.evbuf[w * gper * 64 + (k - L.evoff[w])];
+        Event e = ((const Event *)P.evbuf)[w * gper * 64 + (k - L.evoff[w])];
         const int type = e.info & 0xff, p = (e.info >> 8) & 0xff;
         e.le += L.wavehist[w * nP + p];
         if (type == EV_CALLER) atomicMin(&L.fcall[p], e.idx);
@@ -410,7 +410,7 @@ __device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const i
 
     // every call: scan count `check` (Beta.c:321-330), counters (Beta.c:334,349-351 / WithNOMA:650-652)
     const int npost = L.scal[S_NPOST];
-    int *const sing = (N + nP <= SCAP) ? L.sidx : P.sidx;
+    int *const sing = (N + nP <= SCAP) ? L.sidx : (int *)P.sidx;
     for (int k = tid; k < N + nP; k += WG_THREADS) {
         int idx = 0, p = 0, le = 0;
         bool caller = false;
@@ -468,7 +468,7 @@ __device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const i
         int rank = 0;
         for (int m = 0; m < ns; m++) rank += sing[m] < my ? 1 : 0;
         if (rank < G) {
-            atomicOr(reinterpret_cast<unsigned *>(&P.rec[my]) + 3, PK_GRANT_BIT);
+            grant_rec(&P.rec[my]);
         }
     }
     grantCheck += ns;
@@ -482,14 +482,14 @@ __device__ __forceinline__ void resolve(const TrialDev &P, const Lds &L, const i
 template <bool GLIBC>
 __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__restrict__ params) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const TrialDev P = params[blockIdx.x];
+    const TrialG P(params[blockIdx.x]);
     const Lds L = carve(smem, P.nP);
     const int tid = threadIdx.x;
     const int nUE = P.nUE, nP = P.nP, aT = P.aT;
 
     // calloc + initialUE (Beta.c:78-83)
     for (int i = tid; i < nUE; i += WG_THREADS) {
-        P.rec[i] = make_int4(-1, 0, 0, 0);
+        store_rec(&P.rec[i], make_int4(-1, 0, 0, 0));
         P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0; P.nd[i] = 0;
     }
     for (int k = tid; k < NW * nP; k += WG_THREADS) { L.wavehist[k] = 0; L.smidx[k] = INT_MAX; L.smle[k] = 0; }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__res
     int ptcS = 0, fcS = 0;
     unsigned long long ndS = 0;
     for (int i = tid; i < nUE; i += WG_THREADS) {
-        const int4 r = P.rec[i];
+        const int4 r = load_rec_plain(&P.rec[i]);
         const int act = (r.w >> PK_ACT_SHIFT) & 3, conn = (r.w >> PK_CONN_SHIFT) & 3, pre = (r.w >> PK_PRE_SHIFT) & 0xff,
                   rar = (r.w >> PK_RAR_SHIFT) & 0xff, mrc = (r.w >> PK_MRC_SHIFT) & 0xff;
         const int timer = act == ACT_IDLE ? -1 : (act == ACT_DONE ? r.y : tend - r.y);
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__res
             o.preambleChange = pre != 0; o.rarWindow = rar; o.maxRarCounter = mrc; o.preambleTxCounter = ptc;
             o.msg2Flag = (act == ACT_M3 || act == ACT_DONE); o.connectionRequest = conn == 2 ? 48 : conn;
             o.msg4Flag = act == ACT_DONE; o.failCount = fc;
-            P.logs[i] = o;
+            store_log(P.logs, i, o);
         }
     }
 #pragma unroll
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__res
         o.steps = steps;
         o.sumTimer = *reinterpret_cast<long long *>(&L.scal[S_SUMT_LO]);
         o.dbg[0] = o.dbg[1] = o.dbg[2] = o.dbg[3] = 0;
-        *P.out = o;
+        *(DevResult *)P.out = o;
     }
 }
 

@@ -63,8 +63,8 @@ __device__ __forceinline__ NLds ncarve(char *smem, int nP) {
     return L;
 }
 
-__device__ __forceinline__ long long nld(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void nst(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long nld(const PRACH_G long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void nst(PRACH_G long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ long long nmk(unsigned lo20, unsigned hi20, unsigned tag) {
     const unsigned w0 = (lo20 & 0xFFFFFu) | ((tag & 0xFFFu) << 20), w1 = (hi20 & 0xFFFFFu) | (((tag >> 12) & 0xFu) << 20);
     return (long long)(((unsigned long long)w1 << 32) | w0);
@@ -73,7 +73,7 @@ __device__ __forceinline__ bool nok(long long g, unsigned tag) {
     const unsigned w0 = (unsigned)g, w1 = (unsigned)((unsigned long long)g >> 32);
     return (w0 >> 20) == (tag & 0xFFFu) && ((w1 >> 20) & 0xFu) == ((tag >> 12) & 0xFu);
 }
-__device__ __forceinline__ long long nwait(const long long *p, unsigned tag, int *status_word) {
+__device__ __forceinline__ long long nwait(const PRACH_G long long *p, unsigned tag, int *status_word) {
     long long g = nld(p);
     unsigned spins = 0;
     while (!nok(g, tag)) {
@@ -91,22 +91,22 @@ size_t noma_kernel_lds_bytes(int nP) { return sizeof(double) * 2 * 6 * 64 + size
 __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = blockIdx.x % nT, b = blockIdx.x / nT;
-    const TrialDev P = params[T];
+    const TrialG P(params[T]);
     const NLds L = ncarve(smem, P.nP);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nUE = P.nUE, nP = P.nP, aT = P.aT, nGrantUL = P.nGrantUL, nb = 6 * P.nP;
-    const int *pre0 = P.n_pre0, *sector = P.n_sector;
-    const double *gain = P.n_gain, *lgain = P.n_lgain;
+    const PRACH_G int *pre0 = P.n_pre0, *sector = P.n_sector;
+    const PRACH_G double *gain = P.n_gain, *lgain = P.n_lgain;
     const FastMod fmP = make_fastmod(nP), fmB = make_fastmod(P.backoff), fmA = make_fastmod(aT);
     const int totgroups = (nUE + 63) >> 6;
     const int lgroups = (totgroups + G - 1) / G;
     const int mbstride = 1 + nb; // granules per mailbox: header + bins
-    long long *const mbox = reinterpret_cast<long long *>(P.mbox);
+    PRACH_G long long *const mbox = reinterpret_cast<PRACH_G long long *>(P.mbox);
 
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) { // calloc + initUserInfo (NOMA.c:651-655), own groups
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
         if (g < totgroups && i < nUE) {
-            P.rec[i] = make_int4(0, 0, 0, 0);
+            store_rec(&P.rec[i], make_int4(0, 0, 0, 0));
             P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0; P.nd[i] = 0;
         }
     }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                 r.x = t + 1; r.y = t; r.z = 0;
                 r.w = 1 | (pre0[i] << N_PRE_SHIFT);
                 P.ptc[i] = 1; P.ftt[i] = t + 1; P.nd[i] = P.n_nd0[i];
-                P.rec[i] = r;
+                store_rec(&P.rec[i], r);
             }
             const unsigned pk = (unsigned)r.w;
             // transmitter (NOMA.c:207): RA==0, txTime==time+1, msg2==0, nowBackoff<=0, RaFailed==0
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             nsucc_tot = L.scal[N_NSUCC]; maxt_tot = L.scal[N_MAXT];
             __syncthreads();
         } else {
-            long long *const mygr = mbox + ((size_t)(s & 1) * G + b) * mbstride;
+            PRACH_G long long *const mygr = mbox + ((size_t)(s & 1) * G + b) * mbstride;
             for (int k = tid; k < nb; k += WG_THREADS) {
                 const int wv = L.who[k];
                 nst(mygr + 1 + k, nmk((unsigned)L.cnt[k], wv == INT_MAX ? NGR_NONE : (unsigned)wv, tag));
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             if (count > 0) {
                 const int pos = __popcll(sm & lanemask_lt(lane));
                 if (count <= nGrantUL) { // NOMA.c:252-260
-                    if (single && ((myidx >> 6) % G) == b) atomicOr(reinterpret_cast<unsigned *>(&P.rec[myidx]) + 3, PK_GRANT_BIT);
+                    if (single && ((myidx >> 6) % G) == b) grant_rec(&P.rec[myidx]);
                 } else {
                     if (single) { L.sidx[sct * 64 + pos] = myidx; L.sg[sct * 64 + pos] = gain[myidx]; L.slg[sct * 64 + pos] = lgain[myidx]; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         const unsigned long long lm = __ballot(left);
                         if (left && __popcll(lm & lanemask_lt(lane)) < nGrantUL - grants) grantme = true;
                     }
-                    if (grantme && ((cidx >> 6) % G) == b) atomicOr(reinterpret_cast<unsigned *>(&P.rec[cidx]) + 3, PK_GRANT_BIT);
+                    if (grantme && ((cidx >> 6) % G) == b) grant_rec(&P.rec[cidx]);
                     if (b == 0 && lane == 0 && npd) atomicAdd(&L.scal[N_PAIRD], npd);
                 }
             }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     }
                 }
                 if (nd_loaded) P.nd[i] = k;
-                if (dirty) { r.w = (int)pk; P.rec[i] = r; }
+                if (dirty) { r.w = (int)pk; store_rec(&P.rec[i], r); }
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_maxt = max(c_maxt, __shfl_down(c_maxt, d)); }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
         if (g >= totgroups || i >= nUE) continue;
-        const int4 r = P.rec[i];
+        const int4 r = load_rec_plain(&P.rec[i]);
         const unsigned pk = (unsigned)r.w;
         const int act = pk & 3;
         const bool ra = pk & N_RA_BIT, fail = pk & N_FAIL_BIT;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             o.connectionRequest = (pk & N_M3W_BIT) ? 49 : 0;              // NOMA: msg3Wait
             o.msg4Flag = ra ? 1 : 0;                                      // NOMA: RA
             o.failCount = (fail ? 1 : 0) | (P.fcnt[i] << 16);             // NOMA: RaFailed | msg3Faile << 16
-            P.logs[i] = o;
+            store_log(P.logs, i, o);
         }
     }
 #pragma unroll
@@ -415,15 +415,15 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     }
     __syncthreads();
     if (tid == 0) { // DevResult was zeroed by the engine before the launch
-        DevResult *o = P.out;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&o->sumTimer), *reinterpret_cast<unsigned long long *>(&L.scal[N_SUMT]));
-        atomicAdd(&o->draws, *reinterpret_cast<unsigned long long *>(&L.scal[N_ND]) + (b == 0 ? (unsigned long long)L.scal[N_PAIRD] : 0ull));
-        atomicAdd(&o->ptcSum, L.scal[N_PTC]);
-        atomicAdd(&o->fcSum, L.scal[N_FC]);
-        atomicAdd(&o->nSuccess, L.scal[N_NSUCC]);
-        atomicAdd(&o->finalSuccess, L.scal[N_NSUCC]);
-        if (status != PRACH_OK) atomicMin(&o->status, status);
-        atomicMax(&o->dbg[0], (unsigned long long)(L.scal[N_MAXT] + 1)); // latest success subframe + 1 (host: exit time when all succeeded)
+        PRACH_G DevResult *o = P.out;
+        gadd(&o->sumTimer, *reinterpret_cast<long long *>(&L.scal[N_SUMT]));
+        gadd(&o->draws, *reinterpret_cast<unsigned long long *>(&L.scal[N_ND]) + (b == 0 ? (unsigned long long)L.scal[N_PAIRD] : 0ull));
+        gadd(&o->ptcSum, L.scal[N_PTC]);
+        gadd(&o->fcSum, L.scal[N_FC]);
+        gadd(&o->nSuccess, L.scal[N_NSUCC]);
+        gadd(&o->finalSuccess, L.scal[N_NSUCC]);
+        if (status != PRACH_OK) gmin(&o->status, status);
+        gmax(&o->dbg[0], (unsigned long long)(L.scal[N_MAXT] + 1)); // latest success subframe + 1 (host: exit time when all succeeded)
         if (b == 0) {
             o->time_exit = time_exit;
             o->activeCheck = activeCheck;

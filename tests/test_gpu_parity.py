@@ -419,3 +419,18 @@ def test_gpu_reproduces_reference_random_flags(pkg, engine):
             assert hashlib.sha256(text).hexdigest() == tr["logs_sha256"], what
             checked += 1
     assert checked >= 170
+
+
+def test_dense_pass_option_agrees(pkg, ob, engine):
+    """engine option "dense": the cluster kernel without the compacted two-phase pass (every group through the full
+    per-UE body) gives the same trial, bit for bit."""
+    cases = [(0, 9000, {}), (1, 9000, {}), (1, 5000, dict(nPreamble=3, backoff=2, nGrantUL=2, maxRarWindow=2, maxMsg2TxCount=1))]
+    engine.set("dense", 1)
+    try:
+        for v, n, kw in cases:
+            cfg = pkg.make_cfg(n, variant=v, rng_mode=pkg.RNG_PHILOX, seed=21, **kw)
+            (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+            ores, oues = ob.run_trial(ob.make_cfg(n, variant=v, **kw), ob.Rng(ob.RNG_PHILOX, 21))
+            assert_same(pkg, res, logs, ores, oues, ("dense", v, n, kw))
+    finally:
+        engine.set("dense", 0)
