@@ -153,6 +153,9 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const Ct
 
     // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
     if (MODE != 2 && u.pend != PEND_NONE) {
+        // the compacted pass leaves a UE in steady contention untouched (see cluster_pass_compact): its record dates from
+        // subframe u.tx, since when it has been bumped and has counted one more RAR-window subframe per subframe
+        if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; }
         if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
             u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
             if (u.pend == PEND_RESET) u.bo = 0;
@@ -406,58 +409,54 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
             if (!((word >> (jj & 31)) & 1u)) return jj;
         }
     };
-    auto fetch = [&](int jj, int4 &rr, bool &ok) { // unconditional load, see cluster_pass
-        const int in = (C.b + C.G * max(jj, 0)) * 64 + lane;
-        ok = jj >= 0 && in < activeCheck;
-        rr = load_rec(&P.rec[ok ? in : 0]);
-    };
-    // ---- phase A ----  (records PFD groups ahead; 4 measured no faster batched, slower for a single trial)
-    constexpr int PFD = 2;
-    int jq[PFD];
-    int4 rq[PFD];
-    bool okq[PFD];
-    jq[0] = next_live(w);
-    fetch(jq[0], rq[0], okq[0]);
-#pragma unroll
-    for (int d = 1; d < PFD; d++) {
-        jq[d] = jq[d - 1] >= 0 ? next_live(jq[d - 1] + NW) : -1;
-        fetch(jq[d], rq[d], okq[d]);
-    }
-    while (jq[0] >= 0) {
-        const int j = jq[0];
+    // The prefetch is an unconditional load of an in-range record (lanes past the arrived UEs re-read the last one and
+    // ignore it): nothing has to be merged with a default value, so nothing is waited for before the record is used.
+    const unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
+    auto fetch = [&](int jj) -> int4 { return load_rec(P.rec + min((unsigned)((C.b + C.G * jj) * 64 + lane), lastrec)); };
+    const unsigned rarlim = (unsigned)(maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
+    // ---- phase A ----
+    auto phase_a = [&](const int j, const int4 r) __attribute__((always_inline)) {
         const int g = C.b + C.G * j;
         const int i = g * 64 + lane;
-        const int4 r = okq[0] ? rq[0] : make_int4(-1, 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d + 1 < PFD; d++) { jq[d] = jq[d + 1]; rq[d] = rq[d + 1]; okq[d] = okq[d + 1]; }
-        jq[PFD - 1] = jq[PFD - 2] >= 0 ? next_live(jq[PFD - 2] + NW) : -1;
-        fetch(jq[PFD - 1], rq[PFD - 1], okq[PFD - 1]);
-
-        const bool valid = i < activeCheck;
         const unsigned pk = (unsigned)r.w;
-        const int act = (int)(pk >> PK_ACT_SHIFT) & 3, pre = (int)(pk >> PK_PRE_SHIFT) & 0xff, rar = (int)(pk >> PK_RAR_SHIFT) & 0xff,
-                  pend = (int)(pk >> PK_PEND_SHIFT) & 7;
-        const bool old = valid && i < prevAC;
-        const bool plainbump = (unsigned)(pend - 1) < 2u && !(pk & PK_GRANT_BIT); // PEND_STAY / PEND_CALLER without a grant: txTime++
-        const int tx = plainbump ? t : r.x;
-        const bool isM1 = act == ACT_M1;
-        const bool contend = isM1 && pre != 0 && now_backoff(r.z, t) <= 0;
-        const bool lightc = old && (pend == PEND_NONE || plainbump) && contend && rar + 1 < maxRar;
-        const bool quiet = !valid || (old && pend == PEND_NONE && !contend && !(isM1 && pre == 0) && !((isM1 || act == ACT_M3) && r.x == t));
+        const unsigned pg = pk >> PK_PEND_SHIFT; // deferred outcome | grant bit << 3
+        const bool act2 = (pk & 2u) != 0u;        // ACT_M1 or ACT_M3
+        const bool isM1 = (pk & 3u) == (unsigned)ACT_M1;
+        const bool haspre = (pk & (0xffu << PK_PRE_SHIFT)) != 0u;
+        const bool contend = isM1 && haspre && r.z <= t; // nowBackoff <= 0: stored as expiry subframe when positive
+        const bool trig = r.x == t;
+        // light: PEND_NONE / PEND_STAY / PEND_CALLER without a grant (pg 0..2), contending, RAR window stays open.
+        // A PEND_STAY record may be `age` subframes old (written at subframe r.x, not touched since): rarWindow has grown by age.
+        const int age = pg == (unsigned)PEND_STAY ? t - 1 - r.x : 0;
+        const unsigned rarnow = (pk & (0xffu << PK_RAR_SHIFT)) + ((unsigned)age << PK_RAR_SHIFT);
+        bool lightc = pg < 3u && contend && rarnow < rarlim;
+        bool quiet = pg == 0u && (!act2 || (!contend && !trig && !(isM1 && !haspre)));
+        bool done = (pk & 3u) == (unsigned)ACT_DONE;
+        if (g * 64 + 64 > prevAC) { // the (at most two) groups the arrival front is in: per-lane range checks
+            const bool valid = i < activeCheck, old = i < prevAC;
+            lightc = lightc && old;
+            quiet = !valid || (old && quiet);
+            done = (valid && done) || i >= nUE;
+        }
         const bool heavy = !lightc && !quiet;
         if (!__any(lightc || heavy)) {
             // nothing happens in this group; retire it for good once every UE in it has finished
-            if (__all(i >= nUE || act == ACT_DONE) && lane == 0) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
-            continue;
+            if (__all(done) && lane == 0) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
+            return;
         }
-        if (lightc) {
-            const bool member = tx == t;
-            const unsigned npk = (pk & ~((0xffu << PK_RAR_SHIFT) | (7u << PK_PEND_SHIFT) | PK_GRANT_BIT)) | ((unsigned)(rar + 1) << PK_RAR_SHIFT) |
-                                 (member ? (unsigned)PEND_STAY << PK_PEND_SHIFT : 0u);
-            store_rec(&P.rec[i], make_int4(tx, r.y, r.z, (int)npk));
+        if (lightc) { // Beta.c:245 + the txTime++ of Beta.c:346,358
+            const bool bump = pg != 0u;
+            const bool member = bump || trig; // matched by a preambleCollision scan in this subframe
+            // steady contention (already PEND_STAY): bumped again, one more window subframe, still matched — all of it follows
+            // from the record's age, so the record is NOT rewritten (ue_step brings it up to date when something happens)
+            if (pg != (unsigned)PEND_STAY) {
+                const unsigned npk = ((pk & 0x0FFFFFFFu) + (1u << PK_RAR_SHIFT)) | (member ? (unsigned)PEND_STAY << PK_PEND_SHIFT : 0u);
+                store_rec(P.rec + (unsigned)i, make_int4(bump ? t : r.x, r.y, r.z, (int)npk));
+            }
             if (member) {
-                atomicAdd(&L.hist[pre - 1], 1);
-                if (__atomic_load_n(&L.mloc[pre - 1], __ATOMIC_RELAXED) > i) atomicMin(&L.mloc[pre - 1], i);
+                const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
+                atomicAdd(&L.hist[p1], 1);
+                if (__atomic_load_n(&L.mloc[p1], __ATOMIC_RELAXED) > i) atomicMin(&L.mloc[p1], i);
             }
         }
         const unsigned long long hm = __ballot(heavy);
@@ -476,6 +475,24 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
                            c_succ, c_contf);
             }
         }
+    };
+    // two record slots, refilled alternately: the next group's record is in flight while one is worked on
+    int j0 = next_live(w);
+    int j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
+    int4 r0 = fetch(j0), r1 = fetch(j1);
+    for (;;) {
+        if (j0 < 0) break;
+        const int ja = j0;
+        const int4 ra = r0;
+        j0 = j1 >= 0 ? next_live(j1 + NW) : -1;
+        r0 = fetch(j0);
+        phase_a(ja, ra);
+        if (j1 < 0) break;
+        const int jb = j1;
+        const int4 rb = r1;
+        j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
+        r1 = fetch(j1);
+        phase_a(jb, rb);
     }
     STAMP(4);
     __syncthreads();
