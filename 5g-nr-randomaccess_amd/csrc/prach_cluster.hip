@@ -120,14 +120,69 @@ __device__ __forceinline__ long long wait_granule(const PRACH_G long long *p, un
     return g;
 }
 
-struct Ctx {
+template <bool H8_>
+struct CtxT {
+    static constexpr bool H8 = H8_; // 8 + 4 byte hot record (one workgroup per trial, streaming) or the engine's 16-byte record
     int b, G, evw, mbstride;
     PRACH_G int *mbox;   // [2][G][mbstride ints]: per workgroup 1 header + nP bucket + evw event granules
     PRACH_G v2i_t *cand; // this workgroup's private early-leaver candidate scratch
+    PRACH_G v4i_t *rec;  // [nUE] the 16-byte record (H8 == false)
+    PRACH_G v2i_t *hot;  // [nUE] {packed word, (txTime + 1) | nowBackoff expiry << 16}: all the pass needs of a UE, 8 bytes
+    PRACH_G int *tbase;  // [nUE] timer base (only read when something happens to the UE)
+    int *status_word;    // LDS: a value that does not fit the 8-byte form stops the trial (the engine reruns it on trial_kernel)
 };
 
-__device__ __forceinline__ PRACH_G long long *gr_of(const Ctx &C, int parity, int wg) {
+template <class CX>
+__device__ __forceinline__ PRACH_G long long *gr_of(const CX &C, int parity, int wg) {
     return reinterpret_cast<PRACH_G long long *>(C.mbox + ((size_t)parity * C.G + wg) * C.mbstride);
+}
+
+// With one workgroup per trial (the streaming, batched regime) the hot record (prach_device.h) is kept as 8 + 4 bytes inside
+// the 16 bytes the engine lays out per UE: txTime and the backoff expiry are subframe numbers below 2^16 (the engine checks;
+// longer trials keep the 16-byte form) and the timer base is not needed to decide what a UE does: half the bytes per UE
+// visit.  A cluster (G > 1) keeps the 16-byte record: its state is L2-resident and one load per event is shorter than two.
+constexpr int HOT_BO_BIAS = 2048; // nowBackoff is a literal <= 0 or an expiry subframe; a stale txTime can make the literal negative (Beta.c:266)
+__device__ __forceinline__ int4 hot_decode(const v2i_t h, const int tb) {
+    const unsigned w1 = (unsigned)h.y;
+    return make_int4((int)(w1 & 0xffffu) - 1, tb, (int)(w1 >> 16) - HOT_BO_BIAS, h.x);
+}
+__device__ __forceinline__ v2i_t hot_encode(const int tx, const int bo, const int pk) {
+    v2i_t h;
+    h.x = pk;
+    h.y = (int)(((unsigned)(tx + 1) & 0xffffu) | ((unsigned)(bo + HOT_BO_BIAS) << 16));
+    return h;
+}
+__device__ __forceinline__ bool hot_fits(const int tx, const int bo) { return (unsigned)(tx + 1) <= 0xffffu && (unsigned)(bo + HOT_BO_BIAS) <= 0xffffu; }
+template <class CX>
+__device__ __forceinline__ int4 hot_load_full(const CX &C, const int i) { // non-temporal: the grant bit is set by an L2 atomic
+    if (CX::H8) return hot_decode(__builtin_nontemporal_load(C.hot + (unsigned)i), C.tbase[(unsigned)i]);
+    return load_rec(C.rec + (unsigned)i);
+}
+template <class CX>
+__device__ __forceinline__ void hot_store_full(const CX &C, const int i, const int4 r) {
+    if (CX::H8) {
+        if (!hot_fits(r.x, r.z)) *C.status_word = PRACH_ERR_INTERNAL;
+        C.hot[(unsigned)i] = hot_encode(r.x, r.z, r.w);
+        C.tbase[(unsigned)i] = r.y;
+    } else {
+        store_rec(C.rec + (unsigned)i, r);
+    }
+}
+template <class CX>
+__device__ __forceinline__ void hot_grant(const CX &C, const int i) {
+    if (CX::H8) __hip_atomic_fetch_or(reinterpret_cast<PRACH_G unsigned *>(C.hot + (unsigned)i), PK_GRANT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else grant_rec(C.rec + (unsigned)i);
+}
+// what phase A reads and writes: everything but the timer base
+template <class CX>
+__device__ __forceinline__ int4 hot_load_pass(const CX &C, const unsigned i) {
+    if (CX::H8) return hot_decode(__builtin_nontemporal_load(C.hot + i), 0);
+    return load_rec(C.rec + i);
+}
+template <class CX>
+__device__ __forceinline__ void hot_store_pass(const CX &C, const unsigned i, const int4 r) {
+    if (CX::H8) C.hot[i] = hot_encode(r.x, r.z, r.w);
+    else store_rec(C.rec + i, r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -136,8 +191,8 @@ __device__ __forceinline__ PRACH_G long long *gr_of(const Ctx &C, int parity, in
 // draw counts, MODE 2 select with stream offsets (both need the lanes to be one 64-UE group in index order);
 // MODE 3: only the deferred apply of the last subframe.
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall, const int *lcall,
+template <int MODE, class CX>
+__device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall, const int *lcall,
                                         const int t, const int prevAC, PRACH_G long long *mbev, const unsigned tag, const unsigned long long stepbase,
                                         const int lane, const int g, const int jdead, const int i, const bool valid, const int4 r, unsigned ndc,
                                         int &c_succ, int &c_contf) {
@@ -176,7 +231,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const Ct
         dirty = true;
     }
     if (FINAL) {
-        if (dirty) store_rec(&P.rec[i], pack(u));
+        if (dirty) hot_store_full(C, i, pack(u));
         return;
     }
     // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
@@ -202,7 +257,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const Ct
     if (MODE == 1) { // glibc: this group's rand() calls in the UE loop of subframe t (own pre-step state only)
         const int gs = __popcll(__ballot(need >= 1)) + __popcll(__ballot(need == 2));
         if (lane == 0) L.gsum[g] = gs;
-        if (dirty) store_rec(&P.rec[i], pack(u));
+        if (dirty) hot_store_full(C, i, pack(u));
         return;
     }
 
@@ -320,14 +375,14 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const Ct
         }
     }
     if (nd_dirty) P.nd[i] = ndc;
-    if (dirty) store_rec(&P.rec[i], pack(u));
+    if (dirty) hot_store_full(C, i, pack(u));
 }
 
 // ---------------------------------------------------------------------------------------------
 // dense pass over the groups this workgroup owns (glibc modes, the final apply)
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall, const int *lcall,
+template <int MODE, class CX>
+__device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall, const int *lcall,
                                              const int t, const int prevAC,
                                              const int activeCheck, PRACH_G long long *mbev, const unsigned tag, const unsigned long long stepbase) {
     constexpr bool FINAL = MODE == 3;
@@ -350,7 +405,7 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
     auto fetch = [&](int jj, int4 &rr, unsigned &nn, bool &ok) {
         const int in = (C.b + C.G * max(jj, 0)) * 64 + lane;
         ok = jj >= 0 && in < activeCheck;
-        rr = load_rec(&P.rec[ok ? in : 0]);
+        rr = hot_load_full(C, ok ? in : 0);
         nn = MODE == 0 ? P.nd[ok ? in : 0] : 0u;
     };
     int jA = next_live(w), jB;
@@ -391,7 +446,8 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
 // runs ue_step on the queued UEs 64 at a time, all lanes busy.  ue_step never looks at a lane's neighbours in MODE 0,
 // so the result is the same whichever wavefront a UE lands in.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds &L, const Ctx &C, const FastMods &FM, const int *fcall,
+template <class CX>
+__device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall,
                                                      const int *lcall, const int t, const int prevAC, const int activeCheck, PRACH_G long long *mbev,
                                                      const unsigned tag
 #ifdef PRACH_STAMPS
@@ -412,7 +468,9 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
     // The prefetch is an unconditional load of an in-range record (lanes past the arrived UEs re-read the last one and
     // ignore it): nothing has to be merged with a default value, so nothing is waited for before the record is used.
     const unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
-    auto fetch = [&](int jj) -> int4 { return load_rec(P.rec + min((unsigned)((C.b + C.G * jj) * 64 + lane), lastrec)); };
+    auto fetch = [&](int jj) -> int4 { // H8: 8 bytes per UE, the timer base (.y) is not needed here
+        return hot_load_pass(C, min((unsigned)((C.b + C.G * jj) * 64 + lane), lastrec));
+    };
     const unsigned rarlim = (unsigned)(maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
     // ---- phase A ----
     auto phase_a = [&](const int j, const int4 r) __attribute__((always_inline)) {
@@ -451,7 +509,7 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
             // from the record's age, so the record is NOT rewritten (ue_step brings it up to date when something happens)
             if (pg != (unsigned)PEND_STAY) {
                 const unsigned npk = ((pk & 0x0FFFFFFFu) + (1u << PK_RAR_SHIFT)) | (member ? (unsigned)PEND_STAY << PK_PEND_SHIFT : 0u);
-                store_rec(P.rec + (unsigned)i, make_int4(bump ? t : r.x, r.y, r.z, (int)npk));
+                hot_store_pass(C, (unsigned)i, make_int4(bump ? t : r.x, r.y, r.z, (int)npk));
             }
             if (member) {
                 const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
@@ -470,9 +528,9 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
             } else { // queue full: this wavefront does its events in place
                 if (lane == 0) atomicMin(&L.scal[C_QEND], base);
                 unsigned ndc = 0;
-                if (heavy) ndc = P.nd[i];
-                ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, g, -1, i, heavy, heavy ? r : make_int4(-1, 0, 0, 0), ndc,
-                           c_succ, c_contf);
+                int4 rf = make_int4(-1, 0, 0, 0);
+                if (heavy) { ndc = P.nd[i]; rf = CX::H8 ? make_int4(r.x, C.tbase[(unsigned)i], r.z, r.w) : r; }
+                ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, g, -1, i, heavy, rf, ndc, c_succ, c_contf);
             }
         }
     };
@@ -504,7 +562,7 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
         const int i = v ? L.queue[q0 + lane] : 0;
         int4 r = make_int4(-1, 0, 0, 0);
         unsigned ndc = 0;
-        if (v) { r = load_rec(&P.rec[i]); ndc = P.nd[i]; }
+        if (v) { r = hot_load_full(C, i); ndc = P.nd[i]; }
         ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, i >> 6, -1, i, v, r, ndc, c_succ, c_contf);
     }
 #pragma unroll
@@ -588,7 +646,7 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fca
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
-template <bool GLIBC>
+template <bool GLIBC, bool H8>
 __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = blockIdx.x % nT, b = blockIdx.x / nT;
@@ -600,8 +658,12 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 
     FastMods FM;
     FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
-    Ctx C;
+    CtxT<H8> C;
     C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox;
+    C.status_word = &L.scal[C_STATUS];
+    C.rec = P.rec;
+    C.hot = reinterpret_cast<PRACH_G v2i_t *>(P.rec);
+    C.tbase = reinterpret_cast<PRACH_G int *>(P.rec) + 2 * (size_t)P.nUE;
     const int totgroups = (nUE + 63) >> 6;
     const int lgroups = (totgroups + G - 1) / G; // local groups of any workgroup (upper bound)
     C.cand = P.cand + (size_t)b * lgroups * 64;
@@ -610,7 +672,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
         if (g < totgroups && i < nUE) {
-            store_rec(&P.rec[i], make_int4(-1, 0, 0, 0));
+            hot_store_full(C, i, make_int4(-1, 0, 0, 0));
             P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0; P.nd[i] = 0;
         }
     }
@@ -889,7 +951,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 const int before = L.bins[bin];
                 if (before >= Gr) continue;
                 const int cnt = (bin + 1 < GBINS ? L.bins[bin + 1] : ns) - before;
-                if (before + cnt <= Gr) { if (((my >> 6) % G) == b) grant_rec(&P.rec[my]); }
+                if (before + cnt <= Gr) { if (((my >> 6) % G) == b) hot_grant(C, my); }
                 else { const int s_ = atomicAdd(&L.scal[C_NCROSS], 1); if (s_ < RCCAP) L.rclist[s_] = my; }
             }
             __syncthreads();
@@ -899,7 +961,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 const int my = L.rclist[tid];
                 int rank = L.bins[my >> binshift];
                 for (int m = 0; m < ncross; m++) rank += L.rclist[m] < my ? 1 : 0;
-                if (rank < Gr && ((my >> 6) % G) == b) grant_rec(&P.rec[my]);
+                if (rank < Gr && ((my >> 6) % G) == b) hot_grant(C, my);
             }
         }
         grantCheck += ns;
@@ -924,7 +986,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
         if (g >= totgroups || i >= nUE) continue;
-        const UeState u = unpack(load_rec_plain(&P.rec[i]));
+        const UeState u = unpack(hot_load_full(C, i));
         const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
         const int ptc = P.ptc[i], fc = P.fcnt[i];
         if (u.act == ACT_DONE) { sumT += timer; ptcS += ptc; fcS += fc; }
@@ -980,14 +1042,16 @@ size_t cluster_kernel_lds_bytes(int nP, bool glibc) {
     return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 9 * nP + QCAP + (glibc ? 2 * GSCAP : 0));
 }
 
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, hipStream_t stream) {
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream) {
     const bool glibc = rng_mode == PRACH_RNG_GLIBC;
     const size_t lds = cluster_kernel_lds_bytes(maxP, glibc);
-    const void *fn = glibc ? reinterpret_cast<const void *>(&cluster_kernel<true>) : reinterpret_cast<const void *>(&cluster_kernel<false>);
-    hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    using kernel_t = void (*)(const TrialDev *, int, int);
+    // compact_records: the 8 + 4 byte hot record (streaming regime: one workgroup per trial); else the 16-byte record
+    const kernel_t fn = glibc ? (compact_records ? cluster_kernel<true, true> : cluster_kernel<true, false>)
+                              : (compact_records ? cluster_kernel<false, true> : cluster_kernel<false, false>);
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    if (glibc) hipLaunchKernelGGL(cluster_kernel<true>, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
-    else hipLaunchKernelGGL(cluster_kernel<false>, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
+    hipLaunchKernelGGL(fn, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
     return hipGetLastError();
 }
 

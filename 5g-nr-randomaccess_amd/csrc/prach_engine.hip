@@ -36,6 +36,7 @@ struct prach_engine {
     int64_t opt_cluster = 0;       // workgroups per trial for the Philox cluster kernel (0 = auto)
     int64_t opt_legacy = 0;        // 1: run Philox trials on the one-workgroup trial_kernel as well
     int64_t opt_dense = 0;         // 1: cluster kernel without the compacted pass (diagnostic)
+    int64_t opt_wide_records = 0;  // 1: 16-byte records also with one workgroup per trial (diagnostic)
     int last_G = 0;
     int num_cus = 256;            // co-residency budget of the cluster kernels: one 1024-thread workgroup per CU
 };
@@ -141,6 +142,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "cluster") == 0) { if (value < 0 || value > CLUSTER_MAX_G) return PRACH_ERR_ARG; e->opt_cluster = value; return PRACH_OK; }
     if (std::strcmp(key, "legacy") == 0) { e->opt_legacy = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "dense") == 0) { e->opt_dense = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "wide_records") == 0) { e->opt_wide_records = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }
 
@@ -274,7 +276,16 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(e->arena + lay[k].seeds), reinterpret_cast<int *>(e->arena + lay[k].stream),
                                        (unsigned long long)lay[k].stream_len, e->stream));
     if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
-    else if (G > 0) HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, rng_mode, e->stream));
+    else if (G > 0) {
+        // one workgroup per trial = the streaming regime: 8 + 4 byte hot records, if every subframe number of every trial of
+        // the launch fits 16 bits (txTime <= t + 59 + backoff + accessTime)
+        bool compact = G == 1 && !e->opt_wide_records;
+        for (int k = 0; k < m && compact; k++) {
+            const prach_cfg &c = cfgs[idx[k]];
+            compact = (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 64 < 63000;
+        }
+        HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, rng_mode, compact ? 1 : 0, e->stream));
+    }
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -380,6 +391,7 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
         bool cluster_ok = !e->opt_legacy;
         for (int k : idx) {
             cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
+
             if (mode == PRACH_RNG_GLIBC) cluster_ok = cluster_ok && cfgs[k].nUE <= CLUSTER_GLIBC_MAX_UE;
         }
         if (cluster_ok) {

@@ -434,3 +434,22 @@ def test_dense_pass_option_agrees(pkg, ob, engine):
             assert_same(pkg, res, logs, ores, oues, ("dense", v, n, kw))
     finally:
         engine.set("dense", 0)
+
+
+def test_record_layouts_agree(pkg, ob, engine):
+    """One workgroup per trial keeps 8 + 4 byte hot records (16-bit subframe numbers); the 16-byte form is used when a
+    subframe number may not fit (huge backoff indicator) or on request (engine option "wide_records"): same trials."""
+    cases = [(1, 6000, {}), (0, 6000, dict(uniform=1, nGrantUL=12)), (1, 3000, dict(backoff=60000, nGrantUL=3)),
+             (0, 2500, dict(nPreamble=2, backoff=3, nGrantUL=3, maxRarWindow=2, maxMsg2TxCount=3, accessTime=6))]
+    for wide in (0, 1):
+        engine.set("cluster", 1)
+        engine.set("wide_records", wide)
+        try:
+            for v, n, kw in cases:
+                cfg = pkg.make_cfg(n, variant=v, rng_mode=pkg.RNG_PHILOX, seed=33, **kw)
+                (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+                ores, oues = ob.run_trial(ob.make_cfg(n, variant=v, **kw), ob.Rng(ob.RNG_PHILOX, 33))
+                assert_same(pkg, res, logs, ores, oues, ("wide", wide, v, n, kw))
+        finally:
+            engine.set("cluster", 0)
+            engine.set("wide_records", 0)
