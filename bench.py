@@ -209,7 +209,11 @@ def main():
             extras["config3_sweep_x100_1000_trials"] = {
                 "kernel_updates_per_s": upd / (kms * 1e-3), "kernel_ms": kms, "updates": upd,
                 "roofline": {"bound": "hbm", "achieved": 32.0 * upd / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": 32.0 * upd / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                             "frac": 32.0 * upd / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "algorithmic bytes of the reference's dense formulation (32 B per UE-subframe update, SURVEY 8d); "
+                                     "the kernel skips finished / not yet arrived groups, keeps 8+4 B hot records and does not rewrite a UE "
+                                     "in steady contention, so the algorithmic rate can exceed the HBM peak; PMC traffic of this "
+                                     "launch: profiles/r01f_summary.md"},
                 "mean_success_ratio_100k": sum(r_.nSuccessUE for c, r_ in zip(cfgs, rs) if c.nUE == 100000) / 100 / 1e5}
             # (4) BASELINE config 4: NOMA.c power-level grouping, nUE=100 000, one trial
             cfg = pkg.make_cfg(args.nue, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=0)
