@@ -111,7 +111,12 @@ int prach_run_trials(prach_engine *, const prach_cfg *cfgs, int n, prach_result 
                      prach_ue_log *const *ue_logs);
 int prach_last_timing(const prach_engine *, prach_timing *out);
 
-/* engine tunables (names: "cluster" = workgroups cooperating on one trial, 0 = auto) */
+/* engine tunables; none changes a result, all are covered by parity tests:
+ *   "cluster"       workgroups cooperating on one trial (1..64; 0 = auto)
+ *   "stream_factor" glibc mode: initial draws-per-UE budget of the rand() stream window (0 = auto; it grows on demand)
+ *   "legacy"        1: run on the one-workgroup-per-trial kernel (the exact fallback of every capacity check)
+ *   "dense"         1: cluster kernel without the compacted two-phase pass
+ *   "wide_records"  1: 16-byte hot records also with one workgroup per trial */
 int prach_engine_set(prach_engine *, const char *key, int64_t value);
 
 /* Host-side pieces of the same seam (no device needed) */
