@@ -199,9 +199,9 @@ def glibc_stream(seed, first, n):
 
 
 def format_logs(logs, nUE) -> bytes:
-    n = lib().prach_format_logs(logs, nUE, None, 0)
-    buf = C.create_string_buffer(n + 1)
-    lib().prach_format_logs(logs, nUE, buf, n + 1)
+    cap = nUE * 384 + 1  # a line is at most 378 bytes (prach_host.c): one formatting pass
+    buf = C.create_string_buffer(cap)
+    n = lib().prach_format_logs(logs, nUE, buf, cap)
     return buf.raw[:n]
 
 

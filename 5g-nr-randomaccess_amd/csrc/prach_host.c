@@ -262,20 +262,52 @@ void prach_internal_glibc_seeds(uint32_t seed, uint64_t first, uint64_t nchunks,
 
 /* ---- text surfaces ---------------------------------------------------------------------------- */
 
+/* The per-UE log is 24 MB of text per 100k-UE trial (Beta.c:501-508): once the trial itself takes 85 ms the formatter is
+ * what the caller waits for, so the line is assembled by hand (fixed labels + decimal integers) instead of snprintf. */
+static char *put_int(char *p, int32_t v) {
+    uint32_t u = (uint32_t)v;
+    if (v < 0) { *p++ = '-'; u = 0u - u; }
+    char tmp[10];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + u % 10u); u /= 10u; } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+#define PUT_LIT(s) do { memcpy(p, s, sizeof(s) - 1); p += sizeof(s) - 1; } while (0)
+#define PRACH_LOG_LINE_MAX 384 /* 213 bytes of labels and newline + 15 integers of at most 11 characters = 378 */
+
+static size_t format_log_line(const prach_ue_log *u, char *line) {
+    char *p = line;
+    PUT_LIT("Idx: "); p = put_int(p, u->idx);
+    PUT_LIT(" | Timer: "); p = put_int(p, u->timer);
+    PUT_LIT(" | Active: "); p = put_int(p, u->active);
+    PUT_LIT(" | txTime: "); p = put_int(p, u->txTime);
+    PUT_LIT(" | FirstTxTime: "); p = put_int(p, u->firstTxTime);
+    PUT_LIT(" | SecondTxTime: "); p = put_int(p, u->secondTxTime);
+    PUT_LIT(" | NowBackoff: "); p = put_int(p, u->nowBackoff);
+    PUT_LIT(" | Preamble: "); p = put_int(p, u->preamble);
+    PUT_LIT(" | Preamble change: "); p = put_int(p, u->preambleChange);
+    PUT_LIT(" | RAR window: "); p = put_int(p, u->rarWindow);
+    PUT_LIT(" | Max RAR: "); p = put_int(p, u->maxRarCounter);
+    PUT_LIT(" | Preamble reTx: "); p = put_int(p, u->preambleTxCounter);
+    PUT_LIT(" | MSG 2 Flag: "); p = put_int(p, u->msg2Flag);
+    PUT_LIT(" | ConnectRequest: "); p = put_int(p, u->connectionRequest);
+    PUT_LIT(" | MSG 4 Flag: "); p = put_int(p, u->msg4Flag);
+    *p++ = '\n';
+    return (size_t)(p - line);
+}
+
 size_t prach_format_logs(const prach_ue_log *ue, int nUE, char *buf, size_t cap) {
     size_t off = 0;
-    char line[512];
+    char line[PRACH_LOG_LINE_MAX];
     for (int i = 0; i < nUE; i++) {
-        const prach_ue_log *u = ue + i;
-        int n = snprintf(line, sizeof line,
-                         "Idx: %d | Timer: %d | Active: %d | txTime: %d | FirstTxTime: %d | SecondTxTime: %d | "
-                         "NowBackoff: %d | Preamble: %d | Preamble change: %d | RAR window: %d | Max RAR: %d | "
-                         "Preamble reTx: %d | MSG 2 Flag: %d | ConnectRequest: %d | MSG 4 Flag: %d\n",
-                         u->idx, u->timer, u->active, u->txTime, u->firstTxTime, u->secondTxTime, u->nowBackoff,
-                         u->preamble, u->preambleChange, u->rarWindow, u->maxRarCounter, u->preambleTxCounter,
-                         u->msg2Flag, u->connectionRequest, u->msg4Flag);
-        if (buf && off + (size_t)n <= cap) memcpy(buf + off, line, (size_t)n);
-        off += (size_t)n;
+        if (buf && off + PRACH_LOG_LINE_MAX <= cap) { /* room for any line: format in place */
+            off += format_log_line(ue + i, buf + off);
+            continue;
+        }
+        const size_t n = format_log_line(ue + i, line);
+        if (buf && off + n <= cap) memcpy(buf + off, line, n);
+        off += n;
     }
     return off;
 }
@@ -368,10 +400,10 @@ int prach_write_trial_files(const prach_cfg *c, const prach_result *r, const pra
     snprintf(path, sizeof path, "%s/%s", root, rel);
     if ((rc = write_all(path, text, n)) != 0) return rc;
     if (ue) {
-        size_t need = prach_format_logs(ue, c->nUE, NULL, 0);
-        char *buf = (char *)malloc(need + 1);
+        const size_t cap = (size_t)c->nUE * PRACH_LOG_LINE_MAX + 1;
+        char *buf = (char *)malloc(cap);
         if (!buf) return PRACH_ERR_IO;
-        prach_format_logs(ue, c->nUE, buf, need + 1);
+        const size_t need = prach_format_logs(ue, c->nUE, buf, cap);
         prach_result_file_name(c, 1, rel, sizeof rel);
         snprintf(path, sizeof path, "%s/%s", root, rel);
         rc = write_all(path, buf, need);
