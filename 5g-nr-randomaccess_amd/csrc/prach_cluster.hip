@@ -302,7 +302,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         u.rar++; // Beta.c:245
         dirty = true;
         if (reset) { // Beta.c:250-281
-            if (withnoma) { c_contf++; P.fcnt[i] = P.fcnt[i] + 1; }
+            if (withnoma) { c_contf++; gadd(&P.fcnt[i], 1); }
             const int newp = fastmod(d1, fmP);
             const int tmp = fastmod(d2, fmB);
             u.rar = 0; u.mrc = 0; u.tb = t;
@@ -319,7 +319,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
             }
         } else if (retx) { // Beta.c:282-308
             u.rar = 0; u.mrc++;
-            P.ptc[i] = P.ptc[i] + 1;
+            gadd(&P.ptc[i], 1);
             const int tmp = fastmod(d1, fmB);
             u.tx = slot_align_fm(t + tmp, fmA);
             u.bo = enc_backoff(u.tx - t, t);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         u.bo = enc_backoff(u.tx - t, t);
         u.pre = fastmod(d2, fmP) + 1;
         u.tb = t; u.rar = 0; u.mrc = 0; u.conn = 0;
-        if (withnoma) P.fcnt[i] = P.fcnt[i] + 1;
+        if (withnoma) gadd(&P.fcnt[i], 1);
         if (u.tx == t) { u.pend = PEND_RJOIN; evtype = EVC_RJOIN; evp = u.pre - 1; }
         dirty = true;
     }

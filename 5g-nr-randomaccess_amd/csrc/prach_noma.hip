@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                             alive = false;
                         } else {
                             pk = (pk & ~(0xffu << N_RETX_SHIFT)) | ((unsigned)retx << N_RETX_SHIFT);
-                            P.ptc[i] = P.ptc[i] + 1;
+                            gadd(&P.ptc[i], 1);
                             r.z = enc_backoff(X, t);
                         }
                         dirty = true;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         dirty = true;
                     } else if (m3to) { // NOMA.c:514-543
                         k += 2;
-                        P.fcnt[i] = P.fcnt[i] + 1; // msg3Faile
+                        gadd(&P.fcnt[i], 1); // msg3Faile
                         const int np = fastmod(d1, fmP);
                         const int tmp = fastmod(d2, fmB);
                         r.x = slot_align_fm(r.x + tmp, fmA);
