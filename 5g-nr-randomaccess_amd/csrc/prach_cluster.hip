@@ -565,11 +565,13 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
         if (v) { r = hot_load_full(C, i); ndc = P.nd[i]; }
         ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, i >> 6, -1, i, v, r, ndc, c_succ, c_contf);
     }
+    if (__any((c_succ | c_contf) != 0)) { // (most wavefronts, most subframes: nothing to add)
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
-    if (lane == 0) {
-        if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
-        if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
+        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        if (lane == 0) {
+            if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
+            if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
+        }
     }
 }
 
@@ -921,7 +923,17 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         const int ns = L.scal[C_NS];
         if (ns > SCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
         const int Gr = max(0, P.nGrantUL - 1 - grantCheck); // Beta.c:336-347
-        if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
+        if (Gr > 0 && ns > 0 && ns <= 64) {
+            // up to one wavefront of singleton callers: every lane ranks its own index against the others through
+            // v_readlane — no LDS round trip, no workgroup barrier
+            if (tid < 64) {
+                const int nsu = __builtin_amdgcn_readfirstlane(ns);
+                const int my = tid < nsu ? L.sidx[tid] : INT_MAX;
+                int rank = 0;
+                for (int s_ = 0; s_ < nsu; s_++) rank += __builtin_amdgcn_readlane(my, s_) < my ? 1 : 0;
+                if (tid < nsu && rank < Gr && ((my >> 6) % G) == b) hot_grant(C, my);
+            }
+        } else if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
             // the Gr lowest-index singleton callers, in O(ns): counts per index bin (1024 bins over [0,nUE)),
             // block-wide exclusive prefix, whole bins below the crossing bin are granted, the crossing bin is
             // ranked exactly.  The grant itself is ONE atomicOr into the UE's record by the UE's owner.
