@@ -13,7 +13,8 @@ src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)  # gpurun merges runs into the same directory: take the latest
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 main = max(rows, key=lambda r: float(r["TotalDurationNs"]))
@@ -22,7 +23,7 @@ for kind, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     fs = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
     if not fs:
         continue
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0]))
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(max(fs, key=os.path.getmtime)))
             if r["Counter_Name"] == ctr and r["Kernel_Name"] == main["Name"]]
     pmc[ctr] = vals
     with open(os.path.join(out, f"{tag}_{kind}.csv"), "w") as f:
