@@ -66,7 +66,10 @@ struct CLds {
     int *gpre;    // [GSCAP] their exclusive prefix in index order
 };
 constexpr int GBINS = 1024;
-constexpr int QCAP = 8192;  // event queue of the compacted pass (more: the overflowing wavefront works in place)
+#ifndef PRACH_QCAP
+#define PRACH_QCAP 8192
+#endif
+constexpr int QCAP = PRACH_QCAP; // event queue of the compacted pass (more: the overflowing wavefront works in place)
 constexpr int GSCAP = 4096; // glibc mode on the cluster kernel: at most 4096 groups (262 144 UEs)
 constexpr int MAXG = 64; // the gather's header phase is one wavefront: lane = workgroup
 
