@@ -48,8 +48,8 @@ def test_no_device_fails_loudly(pkg):
 
 def test_product_does_not_reference_oracle():
     """The product path must never route through oracle/ (it is the checker, not the product)."""
-    pk = os.path.join(ROOT, "5g-nr-randomaccess_amd")
-    for dp, _, fns in os.walk(pk):
+    for top in ("5g-nr-randomaccess_amd", "scripts", "include"):
+      for dp, _, fns in os.walk(os.path.join(ROOT, top)):
         for fn in fns:
             if fn.endswith((".py", ".c", ".h", ".hip", ".cpp")) or fn == "Makefile":
                 text = open(os.path.join(dp, fn), errors="ignore").read()

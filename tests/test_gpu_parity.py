@@ -460,12 +460,12 @@ def test_event_queue_overflow_is_exact(pkg):
     """The compacted pass queues the UEs that have an event (8192 per workgroup and subframe); a wavefront that finds the
     queue full does its events in place.  libprach_hip_tinyq.so is the same library built with a 128-entry queue
     (make TINYQ=1 lib; __graft_entry__.build), so ordinary trials overflow it all the time: 250 random configurations
-    (scripts/gpu_fuzz.py: forced cluster sizes, both RNG modes, both record layouts by size) against the oracle."""
+    (tests/tools/gpu_fuzz.py: forced cluster sizes, both RNG modes, both record layouts by size) against the oracle."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "5g-nr-randomaccess_amd", "libprach_hip_tinyq.so")
     assert os.path.exists(lib), "build it: make -C 5g-nr-randomaccess_amd/csrc TINYQ=1 lib"
     env = dict(os.environ, PRACH_LIB=lib)
-    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_fuzz.py"), "31", "250"], env=env, capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "gpu_fuzz.py"), "31", "250"], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "done 250 cases 0 bad" in out.stdout, out.stdout[-2000:]

@@ -1,6 +1,6 @@
 """Development probe: cluster kernel parity + timing for several cluster sizes G. Not a test."""
 import sys, time, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as g
