@@ -2,13 +2,15 @@
 usage: gpu_fuzz.py <seed> <cases> — prints every configuration whose result differs or that errors."""
 import sys
 import time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as g
 from oracle import binding as ob
 import importlib.util
 pkg = g.load_package()
-spec = importlib.util.spec_from_file_location("tgp", "/root/repo/tests/test_gpu_parity.py")
+spec = importlib.util.spec_from_file_location("tgp", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
 tgp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tgp)
 eng = pkg.Engine(0)
 seed, ncase = int(sys.argv[1]), int(sys.argv[2])

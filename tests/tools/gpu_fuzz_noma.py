@@ -1,7 +1,9 @@
 """Fuzz the NOMA.c kernel against its oracle on random configurations (GPU box).  usage: gpu_fuzz_noma.py <seed> <cases>"""
 import sys
 import time
-sys.path.insert(0, "/root/repo")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as g
 from oracle import binding as ob

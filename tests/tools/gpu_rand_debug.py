@@ -1,12 +1,14 @@
 """Debug helper: run the random parity cases one by one and report status / first mismatch."""
 import sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as g
 from oracle import binding as ob
 pkg = g.load_package()
 import importlib.util
-spec = importlib.util.spec_from_file_location("tgp", "/root/repo/tests/test_gpu_parity.py")
+spec = importlib.util.spec_from_file_location("tgp", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
 tgp = importlib.util.module_from_spec(spec); spec.loader.exec_module(tgp)
 eng = pkg.Engine(0)
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 0
