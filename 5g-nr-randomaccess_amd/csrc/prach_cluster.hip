@@ -60,7 +60,10 @@ struct CLds {
     int *evoff;   // [MAXG+1]
     int *bins;    // [GBINS] grant selection: singleton callers per index bin (then exclusive prefix)
     int *wtot;    // [NW]
-    int *hist, *mloc, *total, *fcall, *lcall, *nlv, *fie; // [nP] each
+    int *hist, *mloc, *mloc_stay, *cand_n; // [2][nP] by subframe parity (the kernel hands the pass a view of one parity): pre-members, lowest
+                               // caller (mloc_stay: among the UEs that were already matched in the previous subframe), early-leaver
+                               // candidates per bucket of this workgroup
+    int *total, *fcall, *lcall, *nlv, *fie; // [nP] each ([2][nP]: fcall, lcall)
     int *queue;   // [QCAP] Philox pass: UEs of this workgroup that have an event in this subframe
     int *gsum;    // [GSCAP] glibc mode: rand() calls of every 64-UE group in this subframe's UE loop
     int *gpre;    // [GSCAP] their exclusive prefix in index order
@@ -84,7 +87,7 @@ __device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc) {
     L.evoff = ip; ip += MAXG + 16;
     L.bins = ip; ip += GBINS;
     L.wtot = ip; ip += NW;
-    L.hist = ip; ip += nP; L.mloc = ip; ip += nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
+    L.hist = ip; ip += 2 * nP; L.mloc = ip; ip += 2 * nP; L.mloc_stay = ip; ip += 2 * nP; L.cand_n = ip; ip += 2 * nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
     L.lcall = ip; ip += 2 * nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
     L.queue = ip; ip += QCAP;
     L.gsum = ip; L.gpre = ip + GSCAP; // only carved (and only touched) in glibc mode
@@ -374,7 +377,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_NCAND], __popcll(cm));
             base = __shfl(base, 0);
-            if (eclass) store_i2(&C.cand[base + __popcll(cm & lanemask_lt(lane))], i, oldp);
+            if (eclass) { store_i2(&C.cand[base + __popcll(cm & lanemask_lt(lane))], i, oldp); atomicAdd(&L.cand_n[oldp], 1); }
         }
     }
     if (nd_dirty) P.nd[i] = ndc;
@@ -449,20 +452,29 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
 // runs ue_step on the queued UEs 64 at a time, all lanes busy.  ue_step never looks at a lane's neighbours in MODE 0,
 // so the result is the same whichever wavefront a UE lands in.
 // ---------------------------------------------------------------------------------------------
-template <class CX>
-__device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall,
-                                                     const int *lcall, const int t, const int prevAC, const int activeCheck, PRACH_G long long *mbev,
-                                                     const unsigned tag
-#ifdef PRACH_STAMPS
-                                                     , unsigned long long *stamps, unsigned long long &tprev
-#endif
-                                                     ) {
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// Is a UE whose deferred outcome is none / "matched, stays" / "called" (and not granted) in the light case of phase A at
+// subframe t: contending with a RAR window that stays open?  A PEND_STAY record may be `age` subframes old (written at
+// subframe r.x, not touched since): rarWindow has grown by age.  Shared by phase A and by the grant fix-up of the pipeline.
+__device__ __forceinline__ bool light_case(const unsigned pk, const int rx, const int rz, const int t, const unsigned rarlim) {
+    const unsigned pg = pk >> PK_PEND_SHIFT;
+    const bool contend = (pk & 3u) == (unsigned)ACT_M1 && (pk & (0xffu << PK_PRE_SHIFT)) != 0u && rz <= t;
+    const int age = pg == (unsigned)PEND_STAY ? t - 1 - rx : 0;
+    const unsigned rarnow = (pk & (0xffu << PK_RAR_SHIFT)) + ((unsigned)age << PK_RAR_SHIFT);
+    return pg < 3u && contend && rarnow < rarlim;
+}
+
+// Phase A of the compacted pass by wavefronts w0 .. w0+nw-1 of the workgroup.  SPEC: for the NEXT subframe, while the
+// exchange of the current one is in flight (see the kernel).
+template <bool SPEC, class CX>
+__device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall,
+                                                const int *lcall, const int t, const int prevAC, const int activeCheck, PRACH_G long long *mbev,
+                                                const unsigned tag, const int w0, const int nw) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - w0; // this wavefront's rank among the nw taking part
     const int ngroups = (activeCheck + 63) >> 6;
     const int nUE = P.nUE, maxRar = P.maxRarWindow;
     int c_succ = 0, c_contf = 0;
     auto next_live = [&](int jj) -> int { // wave-uniform: group indices live in scalar registers
-        for (;; jj += NW) {
+        for (;; jj += nw) {
             if (C.b + C.G * jj >= ngroups) return -1;
             const unsigned word = __builtin_amdgcn_readfirstlane(L.dead[(jj >> 5) & (DEADW - 1)]);
             if (!((word >> (jj & 31)) & 1u)) return jj;
@@ -486,11 +498,11 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
         const bool haspre = (pk & (0xffu << PK_PRE_SHIFT)) != 0u;
         const bool contend = isM1 && haspre && r.z <= t; // nowBackoff <= 0: stored as expiry subframe when positive
         const bool trig = r.x == t;
-        // light: PEND_NONE / PEND_STAY / PEND_CALLER without a grant (pg 0..2), contending, RAR window stays open.
-        // A PEND_STAY record may be `age` subframes old (written at subframe r.x, not touched since): rarWindow has grown by age.
-        const int age = pg == (unsigned)PEND_STAY ? t - 1 - r.x : 0;
-        const unsigned rarnow = (pk & (0xffu << PK_RAR_SHIFT)) + ((unsigned)age << PK_RAR_SHIFT);
-        bool lightc = pg < 3u && contend && rarnow < rarlim;
+        // light: PEND_NONE / PEND_STAY / PEND_CALLER without a grant (pg 0..2), contending, RAR window stays open
+        bool lightc = light_case(pk, r.x, r.z, t, rarlim);
+        // ahead of the resolver of the previous subframe its grants are not known: a new caller (PEND_CALLER) may get one and
+        // waits for phase B; a matched UE (PEND_STAY) that gets one is taken out again by the granting thread (grant_fixup)
+        if (SPEC && pg == (unsigned)PEND_CALLER) lightc = false;
         bool quiet = pg == 0u && (!act2 || (!contend && !trig && !(isM1 && !haspre)));
         bool done = (pk & 3u) == (unsigned)ACT_DONE;
         if (g * 64 + 64 > prevAC) { // the (at most two) groups the arrival front is in: per-lane range checks
@@ -517,7 +529,8 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
             if (member) {
                 const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
                 atomicAdd(&L.hist[p1], 1);
-                if (__atomic_load_n(&L.mloc[p1], __ATOMIC_RELAXED) > i) atomicMin(&L.mloc[p1], i);
+                int *const ml = pg == (unsigned)PEND_STAY ? L.mloc_stay : L.mloc;
+                if (__atomic_load_n(&ml[p1], __ATOMIC_RELAXED) > i) atomicMin(&ml[p1], i);
             }
         }
         const unsigned long long hm = __ballot(heavy);
@@ -528,6 +541,8 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
             base = __shfl(base, 0);
             if (base + n <= QCAP) {
                 if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = i;
+            } else if (SPEC) { // cannot happen: the kernel runs ahead only if every owned UE fits the queue
+                if (lane == 0) L.scal[C_STATUS] = PRACH_ERR_INTERNAL;
             } else { // queue full: this wavefront does its events in place
                 if (lane == 0) atomicMin(&L.scal[C_QEND], base);
                 unsigned ndc = 0;
@@ -539,25 +554,38 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
     };
     // two record slots, refilled alternately: the next group's record is in flight while one is worked on
     int j0 = next_live(w);
-    int j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
+    int j1 = j0 >= 0 ? next_live(j0 + nw) : -1;
     int4 r0 = fetch(j0), r1 = fetch(j1);
     for (;;) {
         if (j0 < 0) break;
         const int ja = j0;
         const int4 ra = r0;
-        j0 = j1 >= 0 ? next_live(j1 + NW) : -1;
+        j0 = j1 >= 0 ? next_live(j1 + nw) : -1;
         r0 = fetch(j0);
         phase_a(ja, ra);
         if (j1 < 0) break;
         const int jb = j1;
         const int4 rb = r1;
-        j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
+        j1 = j0 >= 0 ? next_live(j0 + nw) : -1;
         r1 = fetch(j1);
         phase_a(jb, rb);
     }
-    STAMP(4);
-    __syncthreads();
-    STAMP(5);
+    if (!SPEC && __any((c_succ | c_contf) != 0)) { // (only the in-place overflow path counts here)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        if (lane == 0) {
+            if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
+            if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
+        }
+    }
+}
+
+// Phase B: the queued UEs through the full body, 64 at a time, all wavefronts.
+template <class CX>
+__device__ __forceinline__ void compact_phase_b(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall,
+                                                const int *lcall, const int t, const int prevAC, PRACH_G long long *mbev, const unsigned tag) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int c_succ = 0, c_contf = 0;
     // ---- phase B ----
     const int qn = min(L.scal[C_QN], L.scal[C_QEND]);
     for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
@@ -577,6 +605,7 @@ __device__ __forceinline__ void cluster_pass_compact(const TrialG &P, const CLds
         }
     }
 }
+
 
 // One gathered event against the lowest DEFINITE caller of every bucket (complete after round 1).
 __device__ __forceinline__ void classify_event(const CLds &L, int *fcallA, const int k, const int2 ev) {
@@ -682,7 +711,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         }
     }
     for (int k = tid; k < nP; k += WG_THREADS) {
-        L.hist[k] = 0; L.mloc[k] = INT_MAX; L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.fcall[nP + k] = INT_MAX; L.lcall[nP + k] = -1;
+        L.hist[k] = 0; L.mloc[k] = INT_MAX; L.mloc_stay[k] = INT_MAX; L.cand_n[k] = 0;
+        L.hist[nP + k] = 0; L.mloc[nP + k] = INT_MAX; L.mloc_stay[nP + k] = INT_MAX; L.cand_n[nP + k] = 0;
+        L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.fcall[nP + k] = INT_MAX; L.lcall[nP + k] = -1;
         L.nlv[k] = 0; L.fie[k] = 0;
     }
     if (tid < 64) L.scal[tid] = tid == C_QEND ? QCAP : 0;
@@ -699,6 +730,15 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     unsigned long long statN = 0, maxN = 0, statRC = 0, statNS = 0, maxNS = 0;
 #endif
 
+    // Software pipeline of a cluster (G > 1, Philox): phase A of subframe t+1 runs on half of the wavefronts while the other
+    // half gathers the exchange of subframe t — it needs nothing of that exchange's outcome except the grants, and the UEs a
+    // grant could go to are left for phase B (compact_phase_a<true>).  Needs every owned UE to fit the event queue.
+    const bool pipelined = !GLIBC && !P.dense_pass && P.pipeline && G > 1 && lgroups * 64 <= QCAP;
+    int ahead_for = -1; // subframe whose phase A has already run
+    auto parity_view = [&](const int par) { CLds V = L; V.hist = L.hist + par * nP; V.mloc = L.mloc + par * nP; V.mloc_stay = L.mloc_stay + par * nP; V.cand_n = L.cand_n + par * nP; return V; };
+
+    const unsigned rarlim_k = (unsigned)(P.maxRarWindow - 1) << PK_RAR_SHIFT;
+
     for (int t = 0; t < P.stop && status == PRACH_OK; t++) {
         steps++;
         tlast = t;
@@ -713,6 +753,24 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         // the pass (apply of the previous subframe) reads [B]
         int *const fcallA = L.fcall + parity * nP, *const lcallA = L.lcall + parity * nP;
         int *const fcallB = L.fcall + (parity ^ 1) * nP, *const lcallB = L.lcall + (parity ^ 1) * nP;
+        const CLds Lc = parity_view(parity), Ln = parity_view(parity ^ 1); // per-bucket counts of this subframe / of the next one
+        // An UL grant: the grant bit into the UE's record.  If phase A of subframe t+1 has already run it took a matched UE
+        // (PEND_STAY) for steadily contending, counted it into its bucket and did not queue it: take it out again and queue
+        // it.  A granted UE was the only caller of a bucket nobody else stayed matched in, so it is the only one that phase A
+        // counted there as matched before (mloc_stay).  (Every owned UE fits the queue when the kernel runs ahead.)
+        auto grant = [&](const int my) {
+            hot_grant(C, my);
+            if (ahead_for == t + 1) {
+                const int4 r = hot_load_pass(C, (unsigned)my);
+                const unsigned pk = (unsigned)r.w & ~PK_GRANT_BIT;
+                if ((pk >> PK_PEND_SHIFT) == (unsigned)PEND_STAY && light_case(pk, r.x, r.z, t + 1, rarlim_k)) {
+                    const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
+                    atomicSub(&Ln.hist[p1], 1);
+                    Ln.mloc_stay[p1] = INT_MAX;
+                    L.queue[atomicAdd(&L.scal[C_QN], 1)] = my; // ... and its grant is applied by phase B of subframe t+1
+                }
+            }
+        };
 
         if (GLIBC) {
             // glibc mode: every draw's position in the reference's rand() stream = draws of earlier subframes + the
@@ -720,7 +778,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             // Pass X counts per 64-UE group; the counts of all groups are exchanged (2 per granule) and scanned.
             const unsigned long long actdraws = withnoma ? 2ull * (unsigned long long)(activeCheck - prevAC) : 0ull;
             const int ngroups_t = (activeCheck + 63) >> 6;
-            cluster_pass<1>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+            cluster_pass<1>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
             __syncthreads();
             if (G > 1) {
                 const int nq = (lgroups + 1) >> 1;
@@ -759,15 +817,18 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
             const unsigned long long tot = actdraws + (unsigned long long)L.scal[C_GTOT];
             if (base + tot > P.stream_len) { status = PRACH_ERR_STREAM; time_exit = t; break; } // engine retries with a larger window
-            cluster_pass<2>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, base + actdraws);
+            cluster_pass<2>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, base + actdraws);
             base += tot;
         } else {
-            if (P.dense_pass) cluster_pass<0>(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
-            else cluster_pass_compact(P, L, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag
-#ifdef PRACH_STAMPS
-                                      , stamps, tprev
-#endif
-                                      );
+            if (P.dense_pass) {
+                cluster_pass<0>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+            } else {
+                if (ahead_for != t) {
+                    compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0, NW);
+                    __syncthreads(); // the queue is complete
+                }
+                compact_phase_b(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag);
+            }
         }
         __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
         STAMP(0);
@@ -776,7 +837,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         const int ncand = L.scal[C_NCAND];
         for (int k = tid; k < ncand; k += WG_THREADS) {
             const v2i_t c = C.cand[k];
-            if (c.x < L.mloc[c.y]) {
+            if (c.x < min(Lc.mloc[c.y], Lc.mloc_stay[c.y])) {
                 const int slot = atomicAdd(&L.scal[C_NEV], 1);
                 const int info = EVC_LEAVER | (c.y << 4);
                 if (G == 1) { if (slot < EVCAPC) L.gev[slot] = make_int2(c.x, info); }
@@ -784,50 +845,73 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             }
         }
         for (int k = tid; k < nP; k += WG_THREADS) { fcallB[k] = INT_MAX; lcallB[k] = -1; L.total[k] = 0; L.nlv[k] = 0; L.fie[k] = 0; } // ready for the gathers
-        if (tid == 0) { L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; }
+        if (tid == 0) { L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP; } // (the queue has been consumed)
         __syncthreads(); // S2
         int N;
         if (G == 1) {
             // one workgroup owns the whole trial: its histogram / lowest callers ARE the totals; events are in LDS
             const int nevraw = L.scal[C_NEV];
             for (int k = tid; k < nP; k += WG_THREADS) {
-                L.total[k] = L.hist[k]; fcallA[k] = L.mloc[k];
-                L.hist[k] = 0; L.mloc[k] = INT_MAX;
+                L.total[k] = Lc.hist[k]; fcallA[k] = min(Lc.mloc[k], Lc.mloc_stay[k]);
+                Lc.hist[k] = 0; Lc.mloc[k] = INT_MAX; Lc.mloc_stay[k] = INT_MAX; Lc.cand_n[k] = 0;
             }
             if (nevraw > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
             N = nevraw;
             __syncthreads(); // S3
-            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NSUCCTOT] = L.scal[C_NSUCC]; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP; }
+            if (tid == 0) { L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_NSUCCTOT] = L.scal[C_NSUCC]; }
             STAMP(1); STAMP(2);
             // classify the events: reset-cycle candidates, Msg3 re-entries, early leavers below / callers at the first call
             for (int k = tid; k < N; k += WG_THREADS) classify_event(L, fcallA, k, L.gev[k]);
         } else {
-            // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating
-            // granules; the publishing thread also clears its histogram slot for the next pass
+            // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
             for (int k = tid; k < nP; k += WG_THREADS) {
-                const int ml = L.mloc[k];
-                st_sc1_64(mygr + 1 + k, mk_granule((unsigned)L.hist[k], ml == INT_MAX ? GR_NONE : (unsigned)ml, tag));
-                L.hist[k] = 0; L.mloc[k] = INT_MAX;
+                const int ml = min(Lc.mloc[k], Lc.mloc_stay[k]);
+                st_sc1_64(mygr + 1 + k, mk_granule((unsigned)Lc.hist[k], ml == INT_MAX ? GR_NONE : (unsigned)ml, tag));
             }
             if (tid == 0) {
                 const int nevraw = L.scal[C_NEV];
                 st_sc1_64(mygr, mk_granule((unsigned)min(nevraw, C.evw) | (nevraw > C.evw ? (1u << 13) : 0u), (unsigned)L.scal[C_NSUCC], tag));
-                L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP;
+                L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0;
             }
             STAMP(1);
-            // round 1: the bucket granules of every workgroup (all threads) and, on the last wavefront, the headers
-            for (int k = tid; k < G * nP; k += WG_THREADS) {
+            // round 1: the bucket granules of every workgroup and, on the last wavefront, the headers.  The loads are issued,
+            // then (pipelined) phase A of the NEXT subframe runs while they and the other workgroups' stores are in flight,
+            // then every granule is checked and, if its tag is still the old one, re-read until it arrives.
+            const bool ahead = pipelined && t + 1 < P.stop;
+            long long gv[4]; // the first four sweeps cover 4096 bucket granules (G = 64 with 54 preambles: 3456)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = tid + u * WG_THREADS;
+                gv[u] = 0;
+                if (k < G * nP) { const int wg = k / nP, p = k - wg * nP; gv[u] = ld_sc1_64(gr_of(C, parity, wg) + 1 + p); }
+            }
+            long long hv = 0;
+            if (tid >= WG_THREADS - 64 && tid - (WG_THREADS - 64) < G) hv = ld_sc1_64(gr_of(C, parity, tid - (WG_THREADS - 64)));
+            if (ahead) {
+                // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the
+                // pass of subframe t left them
+                const int acNext = ((t + 1) % aT == 0 && activeCheck != nUE) ? P.sched[(t + 1) / aT] : activeCheck;
+                compact_phase_a<true>(P, Ln, C, FM, nullptr, nullptr, t + 1, activeCheck, acNext, nullptr, 0u, 0, NW);
+            }
+            auto take_bucket = [&](const int k, long long g_, const bool fetched) {
                 const int wg = k / nP, p = k - wg * nP;
-                const long long g_ = wait_granule(gr_of(C, parity, wg) + 1 + p, tag, &L.scal[C_STATUS]);
+                if (!fetched || !granule_ok(g_, tag)) g_ = wait_granule(gr_of(C, parity, wg) + 1 + p, tag, &L.scal[C_STATUS]);
                 const unsigned h = (unsigned)g_ & 0xFFFFFu, ml = (unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu;
                 if (h) atomicAdd(&L.total[p], (int)h);
                 if (ml != GR_NONE) atomicMin(&fcallA[p], (int)ml);
+            };
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = tid + u * WG_THREADS;
+                if (k < G * nP) take_bucket(k, gv[u], true);
             }
+            for (int k = tid + 4 * WG_THREADS; k < G * nP; k += WG_THREADS) take_bucket(k, 0ll, false); // (more than 4096 bucket granules)
             if (tid >= WG_THREADS - 64) {
                 const int l = tid - (WG_THREADS - 64);
                 int nev = 0, nsuc = 0, ovf = 0;
                 if (l < G) {
-                    const long long g_ = wait_granule(gr_of(C, parity, l), tag, &L.scal[C_STATUS]);
+                    long long g_ = hv;
+                    if (!granule_ok(g_, tag)) g_ = wait_granule(gr_of(C, parity, l), tag, &L.scal[C_STATUS]);
                     const unsigned w0 = (unsigned)g_ & 0xFFFFFu;
                     nev = (int)(w0 & 0x1FFFu); ovf = (int)((w0 >> 13) & 1u); nsuc = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu);
                 }
@@ -840,8 +924,10 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 if (l == 63) L.scal[C_NTOT] = x;
                 if (l == 0) { L.scal[C_NSUCCTOT] = nsuc; L.scal[C_OVF] = ovf; }
             }
-            __syncthreads(); // S3: totals, lowest definite callers, event offsets
+            if (ahead) ahead_for = t + 1;
+            __syncthreads(); // S3: totals, lowest definite callers, event offsets (and the next subframe's phase A)
             STAMP(2);
+            for (int k = tid; k < nP; k += WG_THREADS) { Lc.hist[k] = 0; Lc.mloc[k] = INT_MAX; Lc.mloc_stay[k] = INT_MAX; Lc.cand_n[k] = 0; } // this parity is used again in two subframes
             if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
             N = L.scal[C_NTOT];
             if (L.scal[C_OVF] || N > EVCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine falls back to trial_kernel
@@ -934,7 +1020,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 const int my = tid < nsu ? L.sidx[tid] : INT_MAX;
                 int rank = 0;
                 for (int s_ = 0; s_ < nsu; s_++) rank += __builtin_amdgcn_readlane(my, s_) < my ? 1 : 0;
-                if (tid < nsu && rank < Gr && ((my >> 6) % G) == b) hot_grant(C, my);
+                if (tid < nsu && rank < Gr && ((my >> 6) % G) == b) grant(my);
             }
         } else if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
             // the Gr lowest-index singleton callers, in O(ns): counts per index bin (1024 bins over [0,nUE)),
@@ -966,7 +1052,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 const int before = L.bins[bin];
                 if (before >= Gr) continue;
                 const int cnt = (bin + 1 < GBINS ? L.bins[bin + 1] : ns) - before;
-                if (before + cnt <= Gr) { if (((my >> 6) % G) == b) hot_grant(C, my); }
+                if (before + cnt <= Gr) { if (((my >> 6) % G) == b) grant(my); }
                 else { const int s_ = atomicAdd(&L.scal[C_NCROSS], 1); if (s_ < RCCAP) L.rclist[s_] = my; }
             }
             __syncthreads();
@@ -976,7 +1062,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 const int my = L.rclist[tid];
                 int rank = L.bins[my >> binshift];
                 for (int m = 0; m < ncross; m++) rank += L.rclist[m] < my ? 1 : 0;
-                if (rank < Gr && ((my >> 6) % G) == b) hot_grant(C, my);
+                if (rank < Gr && ((my >> 6) % G) == b) grant(my);
             }
         }
         grantCheck += ns;
@@ -1054,7 +1140,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 }
 
 size_t cluster_kernel_lds_bytes(int nP, bool glibc) {
-    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 9 * nP + QCAP + (glibc ? 2 * GSCAP : 0));
+    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 15 * nP + QCAP + (glibc ? 2 * GSCAP : 0));
 }
 
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream) {

@@ -68,6 +68,7 @@ struct TrialDev {
     unsigned *bar;               // arrival counter (zeroed before every launch)
     int2 *cand;                  // early-leaver candidate scratch, nUE + 64*G entries
     int dense_pass;              // 1: every group through the full per-UE body (diagnostic option); 0: compacted pass
+    int pipeline;                // 1: clusters run phase A of the next subframe during the exchange of the current one
     // NOMA.c variant (prach_noma.hip) only: the host-built activation table
     const int *n_pre0, *n_sector;
     const double *n_gain, *n_lgain;

@@ -37,6 +37,7 @@ struct prach_engine {
     int64_t opt_legacy = 0;        // 1: run Philox trials on the one-workgroup trial_kernel as well
     int64_t opt_dense = 0;         // 1: cluster kernel without the compacted pass (diagnostic)
     int64_t opt_wide_records = 0;  // 1: 16-byte records also with one workgroup per trial (diagnostic)
+    int64_t opt_pipeline = 1;      // 0: clusters do not run phase A ahead of the exchange (diagnostic)
     int last_G = 0;
     int num_cus = 256;            // co-residency budget of the cluster kernels: one 1024-thread workgroup per CU
 };
@@ -143,6 +144,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "legacy") == 0) { e->opt_legacy = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "dense") == 0) { e->opt_dense = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "wide_records") == 0) { e->opt_wide_records = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "pipeline") == 0) { e->opt_pipeline = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }
 
@@ -212,6 +214,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.seed_lo = (unsigned)c.seed; d.seed_hi = (unsigned)(c.seed >> 32);
         d.stream_len = L.stream_len;
         d.dense_pass = e->opt_dense ? 1 : 0;
+        d.pipeline = e->opt_pipeline ? 1 : 0;
         char *A = e->arena;
         d.rec = reinterpret_cast<int4 *>(A + L.rec);
         d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);

@@ -116,7 +116,8 @@ int prach_last_timing(const prach_engine *, prach_timing *out);
  *   "stream_factor" glibc mode: initial draws-per-UE budget of the rand() stream window (0 = auto; it grows on demand)
  *   "legacy"        1: run on the one-workgroup-per-trial kernel (the exact fallback of every capacity check)
  *   "dense"         1: cluster kernel without the compacted two-phase pass
- *   "wide_records"  1: 16-byte hot records also with one workgroup per trial */
+ *   "wide_records"  1: 16-byte hot records also with one workgroup per trial
+ *   "pipeline"      0: a cluster does not run phase A of the next subframe during the exchange of the current one */
 int prach_engine_set(prach_engine *, const char *key, int64_t value);
 
 /* Host-side pieces of the same seam (no device needed) */

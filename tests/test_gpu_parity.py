@@ -437,6 +437,25 @@ def test_dense_pass_option_agrees(pkg, ob, engine):
         engine.set("dense", 0)
 
 
+def test_pipeline_option_agrees(pkg, ob, engine):
+    """A cluster runs phase A of subframe t+1 while the exchange of subframe t is in flight (UEs that then receive a grant are
+    taken out of their bucket again and queued); engine option "pipeline" 0 keeps the two strictly one after the other."""
+    cases = [(0, 12000, {}), (1, 12000, {}), (0, 4000, dict(uniform=1, nGrantUL=12)),
+             (1, 6000, dict(nPreamble=3, backoff=2, nGrantUL=30, maxRarWindow=3, maxMsg2TxCount=1))]
+    for pipe in (0, 1):
+        engine.set("pipeline", pipe)
+        engine.set("cluster", 4)
+        try:
+            for v, n, kw in cases:
+                cfg = pkg.make_cfg(n, variant=v, rng_mode=pkg.RNG_PHILOX, seed=17, **kw)
+                (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+                ores, oues = ob.run_trial(ob.make_cfg(n, variant=v, **kw), ob.Rng(ob.RNG_PHILOX, 17))
+                assert_same(pkg, res, logs, ores, oues, ("pipeline", pipe, v, n, kw))
+        finally:
+            engine.set("pipeline", 1)
+            engine.set("cluster", 0)
+
+
 def test_record_layouts_agree(pkg, ob, engine):
     """One workgroup per trial keeps 8 + 4 byte hot records (16-bit subframe numbers); the 16-byte form is used when a
     subframe number may not fit (huge backoff indicator) or on request (engine option "wide_records"): same trials."""
