@@ -463,18 +463,18 @@ __device__ __forceinline__ bool light_case(const unsigned pk, const int rx, cons
     return pg < 3u && contend && rarnow < rarlim;
 }
 
-// Phase A of the compacted pass by wavefronts w0 .. w0+nw-1 of the workgroup.  SPEC: for the NEXT subframe, while the
-// exchange of the current one is in flight (see the kernel).
+// Phase A of the compacted pass.  SPEC: for the NEXT subframe, while the exchange of the current one is in flight (see
+// the kernel).
 template <bool SPEC, class CX>
 __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall,
                                                 const int *lcall, const int t, const int prevAC, const int activeCheck, PRACH_G long long *mbev,
-                                                const unsigned tag, const int w0, const int nw) {
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - w0; // this wavefront's rank among the nw taking part
+                                                const unsigned tag) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ngroups = (activeCheck + 63) >> 6;
     const int nUE = P.nUE, maxRar = P.maxRarWindow;
     int c_succ = 0, c_contf = 0;
     auto next_live = [&](int jj) -> int { // wave-uniform: group indices live in scalar registers
-        for (;; jj += nw) {
+        for (;; jj += NW) {
             if (C.b + C.G * jj >= ngroups) return -1;
             const unsigned word = __builtin_amdgcn_readfirstlane(L.dead[(jj >> 5) & (DEADW - 1)]);
             if (!((word >> (jj & 31)) & 1u)) return jj;
@@ -554,19 +554,19 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     };
     // two record slots, refilled alternately: the next group's record is in flight while one is worked on
     int j0 = next_live(w);
-    int j1 = j0 >= 0 ? next_live(j0 + nw) : -1;
+    int j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
     int4 r0 = fetch(j0), r1 = fetch(j1);
     for (;;) {
         if (j0 < 0) break;
         const int ja = j0;
         const int4 ra = r0;
-        j0 = j1 >= 0 ? next_live(j1 + nw) : -1;
+        j0 = j1 >= 0 ? next_live(j1 + NW) : -1;
         r0 = fetch(j0);
         phase_a(ja, ra);
         if (j1 < 0) break;
         const int jb = j1;
         const int4 rb = r1;
-        j1 = j0 >= 0 ? next_live(j0 + nw) : -1;
+        j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
         r1 = fetch(j1);
         phase_a(jb, rb);
     }
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 cluster_pass<0>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
             } else {
                 if (ahead_for != t) {
-                    compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0, NW);
+                    compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag);
                     __syncthreads(); // the queue is complete
                 }
                 compact_phase_b(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag);
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the
                 // pass of subframe t left them
                 const int acNext = ((t + 1) % aT == 0 && activeCheck != nUE) ? P.sched[(t + 1) / aT] : activeCheck;
-                compact_phase_a<true>(P, Ln, C, FM, nullptr, nullptr, t + 1, activeCheck, acNext, nullptr, 0u, 0, NW);
+                compact_phase_a<true>(P, Ln, C, FM, nullptr, nullptr, t + 1, activeCheck, acNext, nullptr, 0u);
             }
             auto take_bucket = [&](const int k, long long g_, const bool fetched) {
                 const int wg = k / nP, p = k - wg * nP;
