@@ -465,10 +465,10 @@ __device__ __forceinline__ bool light_case(const unsigned pk, const int rx, cons
 
 // Phase A of the compacted pass.  SPEC: for the NEXT subframe, while the exchange of the current one is in flight (see
 // the kernel).
-template <bool SPEC, class CX>
+template <bool SPEC, class CX, class HOOK>
 __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall,
                                                 const int *lcall, const int t, const int prevAC, const int activeCheck, PRACH_G long long *mbev,
-                                                const unsigned tag) {
+                                                const unsigned tag, HOOK &&late_hook) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ngroups = (activeCheck + 63) >> 6;
     const int nUE = P.nUE, maxRar = P.maxRarWindow;
@@ -556,6 +556,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     int j0 = next_live(w);
     int j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
     int4 r0 = fetch(j0), r1 = fetch(j1);
+    bool hooked = false; // late_hook runs once: after this wavefront's first two groups, or at the end if it has fewer
     for (;;) {
         if (j0 < 0) break;
         const int ja = j0;
@@ -569,7 +570,9 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
         r1 = fetch(j1);
         phase_a(jb, rb);
+        if (!hooked) { late_hook(); hooked = true; }
     }
+    if (!hooked) late_hook();
     if (!SPEC && __any((c_succ | c_contf) != 0)) { // (only the in-place overflow path counts here)
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 cluster_pass<0>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
             } else {
                 if (ahead_for != t) {
-                    compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag);
+                    compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, [] {});
                     __syncthreads(); // the queue is complete
                 }
                 compact_phase_b(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag);
@@ -878,20 +881,23 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             // then (pipelined) phase A of the NEXT subframe runs while they and the other workgroups' stores are in flight,
             // then every granule is checked and, if its tag is still the old one, re-read until it arrives.
             const bool ahead = pipelined && t + 1 < P.stop;
-            long long gv[4]; // the first four sweeps cover 4096 bucket granules (G = 64 with 54 preambles: 3456)
+            long long gv[4] = {0, 0, 0, 0}, hv = 0; // the first four sweeps cover 4096 bucket granules (G = 64 with 54 preambles: 3456)
+            auto issue_loads = [&]() {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int k = tid + u * WG_THREADS;
-                gv[u] = 0;
-                if (k < G * nP) { const int wg = k / nP, p = k - wg * nP; gv[u] = ld_sc1_64(gr_of(C, parity, wg) + 1 + p); }
-            }
-            long long hv = 0;
-            if (tid >= WG_THREADS - 64 && tid - (WG_THREADS - 64) < G) hv = ld_sc1_64(gr_of(C, parity, tid - (WG_THREADS - 64)));
+                for (int u = 0; u < 4; u++) {
+                    const int k = tid + u * WG_THREADS;
+                    if (k < G * nP) { const int wg = k / nP, p = k - wg * nP; gv[u] = ld_sc1_64(gr_of(C, parity, wg) + 1 + p); }
+                }
+                if (tid >= WG_THREADS - 64 && tid - (WG_THREADS - 64) < G) hv = ld_sc1_64(gr_of(C, parity, tid - (WG_THREADS - 64)));
+            };
             if (ahead) {
                 // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the
-                // pass of subframe t left them
+                // pass of subframe t left them; the round-1 loads go out from inside it (late: the other workgroups' stores have
+                // had time to land, so that few granules have to be read twice)
                 const int acNext = ((t + 1) % aT == 0 && activeCheck != nUE) ? P.sched[(t + 1) / aT] : activeCheck;
-                compact_phase_a<true>(P, Ln, C, FM, nullptr, nullptr, t + 1, activeCheck, acNext, nullptr, 0u);
+                compact_phase_a<true>(P, Ln, C, FM, nullptr, nullptr, t + 1, activeCheck, acNext, nullptr, 0u, issue_loads);
+            } else {
+                issue_loads();
             }
             auto take_bucket = [&](const int k, long long g_, const bool fetched) {
                 const int wg = k / nP, p = k - wg * nP;
