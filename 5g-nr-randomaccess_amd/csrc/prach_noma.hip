@@ -3,6 +3,7 @@
 // A CLUSTER of G workgroups per (seed, nUE) trial (G = 1: one workgroup), Philox draws per (UE, draw#).
 // Ownership of 64-UE groups is static and interleaved (group g -> workgroup g % G, wave (g / G) % 16), so a
 // UE's record never leaves its CU.  Work is organised per 5 ms ACCESS SLOT, not per subframe:
+//   (pass A of slot s+1 runs inside pass B of slot s: one sweep over the records per slot)
 //   pass A   activation of newly arrived UEs from the host-built activation table (activeUE, NOMA.c:131-192:
 //            first preamble, sector, Rayleigh channel gain — prach_noma_activation_table) and the
 //            transmitter gather of preambleSectorCollisionDetection (NOMA.c:206-212) as a 6 x nPreamble
@@ -121,40 +122,49 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     // maxRarWindow > 5 a failed transmitter is never rescheduled (txTime += 3 and rarWindow = 5 is all that happens)
     const bool rar_expires = 5 >= P.maxRarWindow;
 
-    for (int s = 0, t0 = 0; t0 < P.stop && status == PRACH_OK; s++, t0 += aT) {
-        const int t = t0; // the slot's subframe (time % accessTime == 0)
-        const int prevAC = activeCheck;
-        activeCheck = P.sched[s]; // NOMA.c:675-681 (clamped running sum == the arrival table)
-        const unsigned tag = (unsigned)(s + 1);
-        for (int k = tid; k < nb; k += WG_THREADS) { L.cnt[k] = 0; L.who[k] = INT_MAX; L.tcnt[k] = 0; L.twho[k] = INT_MAX; }
-        __syncthreads();
-        // ---- pass A: activation + transmitter gather (own groups) ----
-        const int ngroups = (activeCheck + 63) >> 6;
+    // pass A for one UE of the slot whose subframe is tA: activation of the newly arrived (activeUE, NOMA.c:131-140: everything
+    // else comes from the activation table) and the transmitter gather (NOMA.c:207: RA==0, txTime==time+1, msg2==0,
+    // nowBackoff<=0, RaFailed==0) into this workgroup's (sector, preamble) bins
+    auto pass_a_lane = [&](const int i, int4 &r, bool &dirty, const int tA, const int prevA, const int acA) {
+        if (i >= prevA && i < acA) {
+            r.x = tA + 1; r.y = tA; r.z = 0;
+            r.w = 1 | (pre0[i] << N_PRE_SHIFT);
+            P.ptc[i] = 1; P.ftt[i] = tA + 1; P.nd[i] = P.n_nd0[i];
+            dirty = true;
+        }
+        const unsigned pk = (unsigned)r.w;
+        if (i < acA && (pk & 3) == 1 && !(pk & (N_RA_BIT | N_FAIL_BIT | N_MSG2_BIT)) && r.x == tA + 1 && now_backoff(r.z, tA) <= 0) {
+            const int bin = sector[i] * nP + (int)((pk >> N_PRE_SHIFT) & 0xff);
+            atomicAdd(&L.cnt[bin], 1);
+            atomicMin(&L.who[bin], i);
+        }
+    };
+    for (int k = tid; k < nb; k += WG_THREADS) { L.cnt[k] = 0; L.who[k] = INT_MAX; L.tcnt[k] = 0; L.twho[k] = INT_MAX; }
+    __syncthreads();
+    if (P.stop > 0) { // slot 0: its pass A on its own; every later slot's pass A rides on the previous slot's pass B (one sweep)
+        const int ac0 = P.sched[0];
         for (int j = w;; j += NW) {
             const int g = b + G * j;
-            if (g >= ngroups) break;
+            if (g >= (ac0 + 63) >> 6) break;
             const int i = g * 64 + lane;
-            if (i >= activeCheck) continue;
-            int4 r = load_rec(&P.rec[i]);
-            if (i >= prevAC) { // activeUE (NOMA.c:131-140): everything else comes from the activation table
-                r.x = t + 1; r.y = t; r.z = 0;
-                r.w = 1 | (pre0[i] << N_PRE_SHIFT);
-                P.ptc[i] = 1; P.ftt[i] = t + 1; P.nd[i] = P.n_nd0[i];
-                store_rec(&P.rec[i], r);
-            }
-            const unsigned pk = (unsigned)r.w;
-            // transmitter (NOMA.c:207): RA==0, txTime==time+1, msg2==0, nowBackoff<=0, RaFailed==0
-            if ((pk & 3) == 1 && !(pk & (N_RA_BIT | N_FAIL_BIT | N_MSG2_BIT)) && r.x == t + 1 && now_backoff(r.z, t) <= 0) {
-                const int bin = sector[i] * nP + (int)((pk >> N_PRE_SHIFT) & 0xff);
-                atomicAdd(&L.cnt[bin], 1);
-                atomicMin(&L.who[bin], i);
-            }
+            int4 r = make_int4(0, 0, 0, 0);
+            bool dirty = false;
+            pass_a_lane(i, r, dirty, 0, 0, ac0); // (nothing is active before slot 0: no record to load)
+            if (dirty) store_rec(&P.rec[i], r);
         }
-        __syncthreads();
+    }
+    __syncthreads();
+
+    for (int s = 0, t0 = 0; t0 < P.stop && status == PRACH_OK; s++, t0 += aT) {
+        const int t = t0; // the slot's subframe (time % accessTime == 0)
+        activeCheck = P.sched[s]; // NOMA.c:675-681 (clamped running sum == the arrival table)
+        const int acNext = t0 + aT < P.stop ? P.sched[s + 1] : activeCheck; // the next slot's arrivals (none after the last slot)
+        const unsigned tag = (unsigned)(s + 1);
+        const int ngroups = (max(activeCheck, acNext) + 63) >> 6;
         // ---- exchange: totals over the cluster ----
         int nsucc_tot, maxt_tot;
         if (G == 1) {
-            for (int k = tid; k < nb; k += WG_THREADS) { L.tcnt[k] = L.cnt[k]; L.twho[k] = L.who[k]; }
+            for (int k = tid; k < nb; k += WG_THREADS) { L.tcnt[k] = L.cnt[k]; L.twho[k] = L.who[k]; L.cnt[k] = 0; L.who[k] = INT_MAX; }
             nsucc_tot = L.scal[N_NSUCC]; maxt_tot = L.scal[N_MAXT];
             __syncthreads();
         } else {
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             for (int k = tid; k < nb; k += WG_THREADS) {
                 const int wv = L.who[k];
                 nst(mygr + 1 + k, nmk((unsigned)L.cnt[k], wv == INT_MAX ? NGR_NONE : (unsigned)wv, tag));
+                L.cnt[k] = 0; L.who[k] = INT_MAX; // the next slot's gather starts in this slot's pass B
             }
             if (tid == 0) nst(mygr, nmk((unsigned)L.scal[N_NSUCC], (unsigned)(L.scal[N_MAXT] + 1), tag));
             for (int k0 = tid; k0 < G * nb; k0 += 4 * WG_THREADS) { // four granule loads in flight per thread
@@ -270,7 +281,9 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
         //      subframe and the accessTime-1 following ones, all on registers (one load / store per slot) ----
         {
             const int tend_slot = min(t0 + aT, P.stop);
+            const bool has_next = t0 + aT < P.stop;
             int c_succ = 0, c_maxt = -1;
+            for (int k = tid; k < nb; k += WG_THREADS) { L.tcnt[k] = 0; L.twho[k] = INT_MAX; } // (the resolver is done with them)
             for (int j = w;; j += NW) {
                 const int g = b + G * j;
                 if (g >= ngroups) break;
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                 if (i < activeCheck) r = load_rec(&P.rec[i]);
                 unsigned pk = (unsigned)r.w;
                 bool alive = i < activeCheck && !(pk & (N_RA_BIT | N_FAIL_BIT));
-                if (!__any(alive)) continue;
+                if (!__any(alive || (i >= activeCheck && i < acNext))) continue;
                 bool dirty = false, nd_loaded = false;
                 unsigned k = 0;
                 // -- msg2Results (NOMA.c:692-696 -> :449-498) --
@@ -361,7 +374,10 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     }
                 }
                 if (nd_loaded) P.nd[i] = k;
-                if (dirty) { r.w = (int)pk; store_rec(&P.rec[i], r); }
+                r.w = (int)pk;
+                // -- the NEXT slot's pass A on the record as it stands now: one load and one store per UE and slot --
+                if (has_next) pass_a_lane(i, r, dirty, t0 + aT, activeCheck, acNext);
+                if (dirty) store_rec(&P.rec[i], r);
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_maxt = max(c_maxt, __shfl_down(c_maxt, d)); }
