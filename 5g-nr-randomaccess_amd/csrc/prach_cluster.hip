@@ -67,6 +67,7 @@ struct CLds {
     int *queue;   // [QCAP] Philox pass: UEs of this workgroup that have an event in this subframe
     int *gsum;    // [GSCAP] glibc mode: rand() calls of every 64-UE group in this subframe's UE loop
     int *gpre;    // [GSCAP] their exclusive prefix in index order
+    unsigned *gmask; // [4 * GSCAP / 2] compacted glibc pass: per OWN group, lanes that draw once or twice (2 words) / twice (2 words)
 };
 constexpr int GBINS = 1024;
 #ifndef PRACH_QCAP
@@ -90,7 +91,7 @@ __device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc) {
     L.hist = ip; ip += 2 * nP; L.mloc = ip; ip += 2 * nP; L.mloc_stay = ip; ip += 2 * nP; L.cand_n = ip; ip += 2 * nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
     L.lcall = ip; ip += 2 * nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
     L.queue = ip; ip += QCAP;
-    L.gsum = ip; L.gpre = ip + GSCAP; // only carved (and only touched) in glibc mode
+    L.gsum = ip; L.gpre = ip + GSCAP; L.gmask = reinterpret_cast<unsigned *>(ip + 2 * GSCAP); // only carved (and only touched) in glibc mode
     (void)glibc;
     return L;
 }
@@ -195,14 +196,16 @@ __device__ __forceinline__ void hot_store_pass(const CX &C, const unsigned i, co
 // One subframe of the UE loop for the 64 UEs a wavefront holds (lane = UE; the UEs need not be neighbours).
 // MODE 0: fused apply + activate + select (Philox); glibc mode splits it: MODE 1 apply + activate + per-group
 // draw counts, MODE 2 select with stream offsets (both need the lanes to be one 64-UE group in index order);
-// MODE 3: only the deferred apply of the last subframe.
+// MODE 3: only the deferred apply of the last subframe.  MODE 4 / 5: MODE 1 / 2 for UEs out of the event queue (any UE in
+// any lane): a UE's draw count goes into its group's total and into two per-group lane masks, from which MODE 5 takes
+// the index-ordered prefix inside the group.
 // ---------------------------------------------------------------------------------------------
 template <int MODE, class CX>
 __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall, const int *lcall,
                                         const int t, const int prevAC, PRACH_G long long *mbev, const unsigned tag, const unsigned long long stepbase,
                                         const int lane, const int g, const int jdead, const int i, const bool valid, const int4 r, unsigned ndc,
                                         int &c_succ, int &c_contf) {
-    constexpr bool FINAL = MODE == 3;
+    constexpr bool FINAL = MODE == 3, COUNT = MODE == 1 || MODE == 4, SELECT = MODE == 2 || MODE == 5;
     const int aT = P.aT, nUE = P.nUE;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
     const int tp = t - 1;
@@ -213,7 +216,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
     bool dirty = false;
 
     // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
-    if (MODE != 2 && u.pend != PEND_NONE) {
+    if (!SELECT && u.pend != PEND_NONE) {
         // the compacted pass leaves a UE in steady contention untouched (see cluster_pass_compact): its record dates from
         // subframe u.tx, since when it has been bumped and has counted one more RAR-window subframe per subframe
         if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; }
@@ -241,7 +244,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         return;
     }
     // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
-    if (MODE != 2 && valid && i >= prevAC) {
+    if (!SELECT && valid && i >= prevAC) {
         u.act = ACT_M1; u.tx = t + 1; u.tb = t;
         P.ftt[i] = t + 1;
         if (MODE == 0 && withnoma) { ndc = 2; nd_dirty = true; }
@@ -260,9 +263,16 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
     const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
     const bool busy = isM1 || m3due;
 
-    if (MODE == 1) { // glibc: this group's rand() calls in the UE loop of subframe t (own pre-step state only)
-        const int gs = __popcll(__ballot(need >= 1)) + __popcll(__ballot(need == 2));
-        if (lane == 0) L.gsum[g] = gs;
+    if (COUNT) { // glibc: this group's rand() calls in the UE loop of subframe t (own pre-step state only)
+        if (MODE == 1) {
+            const int gs = __popcll(__ballot(need >= 1)) + __popcll(__ballot(need == 2));
+            if (lane == 0) L.gsum[g] = gs;
+        } else if (need >= 1) { // (i >> 6 is the UE's group, whatever lane it sits in)
+            const int gi = i >> 6, jl = (gi - C.b) / C.G, ln = i & 63;
+            atomicAdd(&L.gsum[gi], need);
+            atomicOr(&L.gmask[4 * jl + (ln >> 5)], 1u << (ln & 31));
+            if (need == 2) atomicOr(&L.gmask[4 * jl + 2 + (ln >> 5)], 1u << (ln & 31));
+        }
         if (dirty) hot_store_full(C, i, pack(u));
         return;
     }
@@ -274,7 +284,17 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
     }
 
     int d1 = 0, d2 = 0;
-    if (MODE == 2) { // the reference's own stream: position = draws before this subframe's UE loop + index-ordered prefix
+    if (MODE == 5) { // the reference's own stream, UE out of the queue: prefix inside its group from the two lane masks
+        if (need > 0) {
+            const int gi = i >> 6, jl = (gi - C.b) / C.G, ln = i & 63;
+            const unsigned lo = ln < 32 ? (1u << ln) - 1u : 0xffffffffu, hi = ln < 32 ? 0u : (1u << (ln - 32)) - 1u;
+            const int before = __popc(L.gmask[4 * jl] & lo) + __popc(L.gmask[4 * jl + 1] & hi) + __popc(L.gmask[4 * jl + 2] & lo) +
+                               __popc(L.gmask[4 * jl + 3] & hi);
+            const unsigned long long o = stepbase + (unsigned long long)L.gpre[gi] + (unsigned long long)before;
+            d1 = P.stream[o];
+            if (need > 1) d2 = P.stream[o + 1];
+        }
+    } else if (MODE == 2) { // the reference's own stream: position = draws before this subframe's UE loop + index-ordered prefix
         if (__any(need > 0)) {
             int x = need;
 #pragma unroll
@@ -583,10 +603,11 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     }
 }
 
-// Phase B: the queued UEs through the full body, 64 at a time, all wavefronts.
-template <class CX>
+// Phase B: the queued UEs through the full body, 64 at a time, all wavefronts (MODE 0: Philox; 4 / 5: the two glibc passes).
+template <int MODE, class CX>
 __device__ __forceinline__ void compact_phase_b(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall,
-                                                const int *lcall, const int t, const int prevAC, PRACH_G long long *mbev, const unsigned tag) {
+                                                const int *lcall, const int t, const int prevAC, PRACH_G long long *mbev, const unsigned tag,
+                                                const unsigned long long stepbase) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int c_succ = 0, c_contf = 0;
     // ---- phase B ----
@@ -596,8 +617,8 @@ __device__ __forceinline__ void compact_phase_b(const TrialG &P, const CLds &L, 
         const int i = v ? L.queue[q0 + lane] : 0;
         int4 r = make_int4(-1, 0, 0, 0);
         unsigned ndc = 0;
-        if (v) { r = hot_load_full(C, i); ndc = P.nd[i]; }
-        ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, i >> 6, -1, i, v, r, ndc, c_succ, c_contf);
+        if (v) { r = hot_load_full(C, i); if (MODE == 0) ndc = P.nd[i]; }
+        ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, i >> 6, -1, i, v, r, ndc, c_succ, c_contf);
     }
     if (__any((c_succ | c_contf) != 0)) { // (most wavefronts, most subframes: nothing to add)
 #pragma unroll
@@ -781,7 +802,21 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             // Pass X counts per 64-UE group; the counts of all groups are exchanged (2 per granule) and scanned.
             const unsigned long long actdraws = withnoma ? 2ull * (unsigned long long)(activeCheck - prevAC) : 0ull;
             const int ngroups_t = (activeCheck + 63) >> 6;
-            cluster_pass<1>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+            // compacted (clusters whose owned UEs all fit the event queue): phase A settles the UEs that draw nothing, the
+            // queued ones are counted here (MODE 4) and select behind the count exchange (MODE 5)
+            const bool gcompact = G > 1 && !P.dense_pass && lgroups * 64 <= QCAP;
+            if (gcompact) {
+                for (int x = tid; x < lgroups; x += WG_THREADS) {
+                    const int g = b + G * x;
+                    if (g < totgroups) L.gsum[g] = 0;
+                    L.gmask[4 * x] = 0; L.gmask[4 * x + 1] = 0; L.gmask[4 * x + 2] = 0; L.gmask[4 * x + 3] = 0;
+                }
+                compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, [] {});
+                __syncthreads(); // the queue is complete, the counts are zeroed
+                compact_phase_b<4>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag, 0ull);
+            } else {
+                cluster_pass<1>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
+            }
             __syncthreads();
             if (G > 1) {
                 const int nq = (lgroups + 1) >> 1;
@@ -820,7 +855,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
             const unsigned long long tot = actdraws + (unsigned long long)L.scal[C_GTOT];
             if (base + tot > P.stream_len) { status = PRACH_ERR_STREAM; time_exit = t; break; } // engine retries with a larger window
-            cluster_pass<2>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, base + actdraws);
+            if (gcompact) compact_phase_b<5>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag, base + actdraws);
+            else cluster_pass<2>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, base + actdraws);
             base += tot;
         } else {
             if (P.dense_pass) {
@@ -830,7 +866,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                     compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, [] {});
                     __syncthreads(); // the queue is complete
                 }
-                compact_phase_b(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag);
+                compact_phase_b<0>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag, 0ull);
             }
         }
         __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
@@ -1146,7 +1182,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 }
 
 size_t cluster_kernel_lds_bytes(int nP, bool glibc) {
-    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 15 * nP + QCAP + (glibc ? 2 * GSCAP : 0));
+    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 15 * nP + QCAP + (glibc ? 4 * GSCAP : 0));
 }
 
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream) {
