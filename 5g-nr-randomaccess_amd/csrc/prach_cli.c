@@ -12,7 +12,8 @@
  * variant draws from Philox (the reference's rand() stream position is data dependent there).
  *
  * Extensions (not in the reference): --program beta|withnoma|noma, --rng glibc|philox, --nue N,
- * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N.
+ * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N, --csv FILE (--program beta: the results.csv of
+ * AveragePerformance.py over the --times seeds of every sweep point, written by prach_results_csv_*).
  */
 #define _GNU_SOURCE
 #include "../../include/prach.h"
@@ -68,7 +69,7 @@ static void die(const char *msg) { printf("%s", msg); exit(-1); }
 int main(int argc, char *argv[]) {
     int randomMax = 1, variant = PRACH_VARIANT_WITHNOMA_C, rng = PRACH_RNG_GLIBC, device = 0, want_logs = 1;
     int sweep_lo = 10000, sweep_hi = 100000, sweep_step = 10000; /* WithNOMA:221 */
-    const char *outdir = ".";
+    const char *outdir = ".", *csv_path = NULL;
     /* --program must be known before the defaults are laid down */
     for (int i = 1; i + 1 < argc; i += 2)
         if (strcmp(argv[i], "--program") == 0)
@@ -130,11 +131,14 @@ int main(int argc, char *argv[]) {
             want_logs = atoi(v) != 0;
         } else if (strcmp(a, "--device") == 0) {
             device = atoi(v);
+        } else if (strcmp(a, "--csv") == 0) {
+            csv_path = v;
         } else {
             usage_and_exit();
         }
     }
     base.rng_mode = rng;
+    if (csv_path && variant != PRACH_VARIANT_BETA_C) die("--csv needs --program beta (AveragePerformance.py reads its six-number Results.txt)");
 
     if (variant == PRACH_VARIANT_NOMA_C) { /* NOMA.c main: no banner, one line per trial, "Done" per seed */
         prach_engine *eng = NULL;
@@ -173,6 +177,8 @@ int main(int argc, char *argv[]) {
 
     const int npts = (sweep_hi - sweep_lo) / sweep_step + 1;
     char text[4096];
+    double (*csv_acc)[6] = csv_path ? (double (*)[6])calloc((size_t)npts, sizeof(double[6])) : NULL; /* AveragePerformance.py:8 */
+    if (csv_path && !csv_acc) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
     if (rng == PRACH_RNG_PHILOX) {
         /* Philox trials are independent: the whole --times x sweep grid runs concurrently in ONE call
          * (one workgroup cluster per trial); output order and files are the reference's. */
@@ -205,9 +211,14 @@ int main(int argc, char *argv[]) {
             if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
             if (want_logs) free(logs[k]);
         }
+        if (csv_acc)
+            for (int k = 0; k < npts; k++)
+                for (int s_ = 0; s_ < randomMax; s_++) { /* seed order inside a point, AveragePerformance.py:10-19 */
+                    prach_format_results(&cfgs[s_ * npts + k], &res[s_ * npts + k], lat, text, sizeof text);
+                    prach_results_csv_accumulate(csv_acc[k], text);
+                }
         free(cfgs); free(res); free(logs);
-        prach_engine_destroy(eng);
-        return 0;
+        goto write_csv;
     }
     /* glibc mode: within one seed the sweep is chained through the rand() stream (one srand() per seed, WithNOMA:219-221),
      * but different seeds are independent — so the loop nest is turned inside out: for every nUE point, the trials of ALL
@@ -244,10 +255,22 @@ int main(int argc, char *argv[]) {
                 outlen[s_] += prach_format_stdout(&cfgs[s_], &res[s_], lat, outtxt[s_] + outlen[s_], 1024);
                 rc = prach_write_trial_files(&cfgs[s_], &res[s_], want_logs ? logs[s_] : NULL, lat, outdir);
                 if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+                if (csv_acc) { prach_format_results(&cfgs[s_], &res[s_], lat, text, sizeof text); prach_results_csv_accumulate(csv_acc[k], text); }
             }
         }
         for (int s_ = 0; s_ < randomMax; s_++) { fwrite(outtxt[s_], 1, outlen[s_], stdout); free(outtxt[s_]); if (want_logs) free(logs[s_]); }
         free(offset); free(cfgs); free(res); free(logs); free(outtxt); free(outlen);
+    }
+write_csv:
+    if (csv_acc) { /* one row per sweep point: mean over the seeds, np.around(., 3), csv.writer's float repr and CRLF */
+        FILE *fp = fopen(csv_path, "wb");
+        if (!fp) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(PRACH_ERR_IO)); return 2; }
+        for (int k = 0; k < npts; k++) {
+            const size_t n = prach_results_csv_row(csv_acc[k], randomMax, text, sizeof text);
+            fwrite(text, 1, n, fp);
+        }
+        fclose(fp);
+        free(csv_acc);
     }
     prach_engine_destroy(eng);
     return 0;

@@ -276,6 +276,30 @@ def test_cli_philox_grid_in_one_call(pkg, ob, engine, tmp_path):
             k += 1
 
 
+def test_cli_results_csv(pkg, tmp_path):
+    """prach_sim --program beta --csv: the results.csv AveragePerformance.py would write from the Results.txt files of the
+    same run (mean over the seeds in seed order, np.around(., 3), csv.writer float repr, CRLF), in both RNG modes."""
+    import numpy as np
+    for rng in ("philox", "glibc"):
+        out = tmp_path / rng
+        out.mkdir()
+        (out / "BasicBetaSimulationResults").mkdir()
+        csvf = out / "results.csv"
+        p = subprocess.run([pkg.CLI_PATH, "--program", "beta", "--rng", rng, "--times", "3", "--sweep", "3000:9000:3000", "--out", str(out),
+                            "--logs", "0", "--csv", str(csvf)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        rows = []
+        for n in (3000, 6000, 9000):
+            acc = [0.0] * 6
+            for seed in range(3):  # AveragePerformance.py:10-19
+                data = [float(l.strip()) for l in (out / "BasicBetaSimulationResults" / f"{seed}_54_{n}_Results.txt").read_text().split("\n") if l.strip()]
+                for i in range(6):
+                    acc[i] += data[i]
+            rows.append(",".join(repr(float(x)) for x in np.around(np.array(acc) / 3, 3)) + "\r\n")
+        assert csvf.read_bytes() == "".join(rows).encode()
+    assert subprocess.run([pkg.CLI_PATH, "--csv", "x.csv"], capture_output=True).returncode == 255  # needs --program beta
+
+
 def test_sharded_sweep_driver_two_ranks(pkg, ob, tmp_path):
     """sweep.py (BASELINE config 5 shape) with 2 ranks rehearsed on one GPU (gloo): sharding + ONE all-reduce +
     row gather + results.csv; the aggregate equals the oracle's trial by trial."""
