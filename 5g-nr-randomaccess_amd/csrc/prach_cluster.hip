@@ -10,16 +10,23 @@
 //    UEs (arrived, not finished) is spread over all CUs at every moment.  Finished groups are
 //    skipped through an LDS bitmap.
 //  * ONE exchange per subframe: every workgroup publishes a small record (per-preamble histogram of
-//    pre-members, lowest-index would-be caller per preamble, the special events) into its mailbox
-//    with write-through (sc1) stores, arrives at a monotonic device-scope counter, polls it with
-//    relaxed sc1 loads, then every workgroup gathers all mailboxes with sc1 loads and runs the same
-//    resolver redundantly (cdna_hip_programming.md G16: sc1 payload + one agent-scope atomic per
-//    workgroup + sc1 loads; no release/acquire fence, no plain load of shared words).  Mailboxes are
-//    double-buffered by subframe parity; every spin is bounded.
+//    pre-members, lowest-index would-be caller per preamble, a header, the special events) into its mailbox as
+//    8-byte SELF-VALIDATING GRANULES — {20-bit value | tag} twice, tag = subframe + 1, one write-through (sc1)
+//    store each — and every workgroup gathers all mailboxes with relaxed sc1 loads, re-reading a granule until
+//    its tag is the current one (cdna_hip_programming.md G16 / R2: no counter, no flag, no fence), then runs the
+//    same resolver redundantly.  Mailboxes are double-buffered by subframe parity; every spin is bounded.
 //  * Interleaving rules out index-ordered prefix sums, so the scan count of the first caller of a
 //    bucket is computed set-wise: total - [caller is a pre-member] - #"early leavers" below it, where
 //    only the early leavers below the workgroup's own lowest caller are published (validated against
 //    the prefix formulation in oracle/phase_model.c).
+//
+//  * The Philox pass is COMPACTED (compact_phase_a / _b): a lean sweep settles "nothing to do" and the steady
+//    contention cycle in place — without rewriting the record: a matched UE's state follows from the record's age —
+//    and queues every other UE for the full per-UE body (ue_step), run 64 queued UEs at a time.
+//  * A cluster PIPELINES subframes: phase A of subframe t+1 runs while the exchange of subframe t is in flight
+//    (see the kernel's step loop); a UE that the resolver then grants is taken out of its bucket again.
+//  * The glibc modes (the reference's own rand() stream) split the pass into count / exchange of the counts /
+//    select; clusters run both halves compacted as well.
 //
 // Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351; the
 // decomposition is DESIGN.md §3.
@@ -217,7 +224,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
 
     // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
     if (!SELECT && u.pend != PEND_NONE) {
-        // the compacted pass leaves a UE in steady contention untouched (see cluster_pass_compact): its record dates from
+        // the compacted pass leaves a UE in steady contention untouched (see compact_phase_a): its record dates from
         // subframe u.tx, since when it has been bumped and has counted one more RAR-window subframe per subframe
         if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; }
         if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
