@@ -52,7 +52,7 @@ namespace {
 constexpr int EVC_CALLER = 1, EVC_RESETCAND = 2, EVC_RJOIN = 3, EVC_LEAVER = 4;
 constexpr int EVCAPC = 4096; // gathered events per subframe held in LDS
 constexpr int SCAPC = 2048;  // singleton callers per subframe held in LDS
-constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups)
+constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups): one run of DEADW / NW words per wavefront, see dead_skip
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 enum { C_NSUCC = 0, C_COLL, C_TXOP, C_CONTF, C_NS, C_NRC, C_NRJ, C_STATUS, C_NEV, C_NCAND, C_OVF, C_NSUCCTOT, C_NTOT,
@@ -83,6 +83,34 @@ constexpr int GBINS = 1024;
 constexpr int QCAP = PRACH_QCAP; // event queue of the compacted pass (more: the overflowing wavefront works in place)
 constexpr int GSCAP = 4096; // glibc mode on the cluster kernel: at most 4096 groups (262 144 UEs)
 constexpr int MAXG = 64; // the gather's header phase is one wavefront: lane = workgroup
+
+// Finished groups.  Local group j of a workgroup belongs to wavefront j % NW; its bit sits in that wavefront's own run of
+// words at position j / NW, so a wavefront walking its groups in order finds the next live one with one LDS read and a
+// find-first-set per 32 groups (late in a trial, and in lightly loaded ones, nearly every group is finished).
+constexpr int DEADWW = DEADW / NW; // words per wavefront
+__device__ __forceinline__ void dead_mark(const CLds &L, const int j) { atomicOr(&L.dead[(j % NW) * DEADWW + ((j / NW) >> 5)], 1u << ((j / NW) & 31)); }
+// next live local group >= j of wavefront j % NW whose global group (b + G * j) is below ngroups, or -1 (wave-uniform)
+__device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b, const int G, const int ngroups) {
+    const int w = j & (NW - 1);
+    int m = j / NW;
+    int g = b + G * j; // global group of (w, m); one round of the workgroup's wavefronts further: + G * NW
+    const int gstep = G * NW;
+    if (g >= ngroups) return -1;
+    unsigned word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]);
+    if (!((word >> (m & 31)) & 1u)) return j; // the common case while a trial is busy: the very next group is live
+    for (;;) { // skip finished groups a word at a time
+        const unsigned live = ~word >> (m & 31); // bit k: group m + k is live (zeros shifted in from the top = "not in this word")
+        if (live) {
+            const int k = __builtin_ctz(live);
+            m += k; g += k * gstep;
+            return g >= ngroups ? -1 : w + NW * m;
+        }
+        const int k = 32 - (m & 31);
+        m += k; g += k * gstep;
+        if (g >= ngroups) return -1;
+        word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]);
+    }
+}
 
 __device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc) {
     CLds L;
@@ -286,7 +314,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
 
     if (!__any(busy || dirty)) {
         // nothing happens in this group; retire it for good once every UE in it has finished
-        if (jdead >= 0 && __all(i >= nUE || u.act == ACT_DONE) && lane == 0) atomicOr(&L.dead[(jdead >> 5) & (DEADW - 1)], 1u << (jdead & 31));
+        if (jdead >= 0 && __all(i >= nUE || u.act == ACT_DONE) && lane == 0) dead_mark(L, jdead);
         return;
     }
 
@@ -425,13 +453,7 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
 
     // software pipeline: the next live groups' records (and Philox draw indices) are in flight while the
     // current group is processed
-    auto next_live = [&](int jj) -> int { // wave-uniform: group indices live in scalar registers
-        for (;; jj += NW) {
-            if (C.b + C.G * jj >= ngroups) return -1;
-            const unsigned word = __builtin_amdgcn_readfirstlane(L.dead[(jj >> 5) & (DEADW - 1)]);
-            if (!((word >> (jj & 31)) & 1u)) return jj;
-        }
-    };
+    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups); }; // wave-uniform
     // two groups ahead (slots A, B; three ahead measured slower).  The load itself is unconditional (record 0 is always
     // mapped) and the "nothing there" case is applied where the record is consumed: a conditional load would have to be
     // waited for on the spot to merge it with the default value, which serialises the prefetches.
@@ -500,13 +522,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     const int ngroups = (activeCheck + 63) >> 6;
     const int nUE = P.nUE, maxRar = P.maxRarWindow;
     int c_succ = 0, c_contf = 0;
-    auto next_live = [&](int jj) -> int { // wave-uniform: group indices live in scalar registers
-        for (;; jj += NW) {
-            if (C.b + C.G * jj >= ngroups) return -1;
-            const unsigned word = __builtin_amdgcn_readfirstlane(L.dead[(jj >> 5) & (DEADW - 1)]);
-            if (!((word >> (jj & 31)) & 1u)) return jj;
-        }
-    };
+    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups); }; // wave-uniform
     // The prefetch is an unconditional load of an in-range record (lanes past the arrived UEs re-read the last one and
     // ignore it): nothing has to be merged with a default value, so nothing is waited for before the record is used.
     const unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
@@ -541,7 +557,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         const bool heavy = !lightc && !quiet;
         if (!__any(lightc || heavy)) {
             // nothing happens in this group; retire it for good once every UE in it has finished
-            if (__all(done) && lane == 0) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
+            if (__all(done) && lane == 0) dead_mark(L, j);
             return;
         }
         if (lightc) { // Beta.c:245 + the txTime++ of Beta.c:346,358

@@ -405,7 +405,16 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
             for (int k : idx) minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
             int G = (int)e->opt_cluster;
             const size_t resident = (size_t)e->num_cus * 3 / 4; // every cluster must be co-resident: <= one workgroup per CU, with margin
-            if (G <= 0) { G = 1; while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 + resident / 6 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
+            if (G <= 0) {
+                G = 1;
+                while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 + resident / 6 && G * 2 <= std::max(1, minGroups / 16)) G *= 2;
+                // Uniform arrivals over 60 000 subframes (Beta.c:92-95): only nUE / 60 000 arrivals per subframe, a UE lives some
+                // tens of subframes, finished groups are skipped 32 at a time — the live band is a few groups and one workgroup
+                // steps through a subframe faster than a cluster exchanges (nUE = 100 000: 5.1 vs 6.2 us per subframe)
+                bool light = mode == PRACH_RNG_PHILOX;
+                for (int k : idx) light = light && cfgs[k].uniform && cfgs[k].nUE <= 2000000;
+                if (light) G = 1;
+            }
             while (G > 1 && (size_t)G * idx.size() > resident) G /= 2;
             std::vector<int> todo = idx, fallback;
             for (int attempt = 0; !todo.empty(); attempt++) {
