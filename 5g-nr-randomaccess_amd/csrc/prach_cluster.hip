@@ -84,30 +84,38 @@ constexpr int QCAP = PRACH_QCAP; // event queue of the compacted pass (more: the
 constexpr int GSCAP = 4096; // glibc mode on the cluster kernel: at most 4096 groups (262 144 UEs)
 constexpr int MAXG = 64; // the gather's header phase is one wavefront: lane = workgroup
 
-// Finished groups.  Local group j of a workgroup belongs to wavefront j % NW; its bit sits in that wavefront's own run of
-// words at position j / NW, so a wavefront walking its groups in order finds the next live one with one LDS read and a
-// find-first-set per 32 groups (late in a trial, and in lightly loaded ones, nearly every group is finished).
+// Finished groups.  Local group j of a workgroup belongs to wavefront j % NW.  One workgroup per trial (G == 1: up to 1024
+// groups per wavefront, and late in a trial or in a lightly loaded one nearly all of them finished): the bit sits in that
+// wavefront's own run of words at position j / NW, so a wavefront walking its groups in order finds the next live one with
+// one LDS read and a find-first-set per 32 groups.  A cluster (a few groups per wavefront): plain bit j, tested one by one
+// (the shorter code path; it measured 1 % faster on the single-trial bench).
 constexpr int DEADWW = DEADW / NW; // words per wavefront
-__device__ __forceinline__ void dead_mark(const CLds &L, const int j) { atomicOr(&L.dead[(j % NW) * DEADWW + ((j / NW) >> 5)], 1u << ((j / NW) & 31)); }
+__device__ __forceinline__ void dead_mark(const CLds &L, const int j, const int G) {
+    if (G > 1) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
+    else atomicOr(&L.dead[(j % NW) * DEADWW + ((j / NW) >> 5)], 1u << ((j / NW) & 31));
+}
 // next live local group >= j of wavefront j % NW whose global group (b + G * j) is below ngroups, or -1 (wave-uniform)
 __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b, const int G, const int ngroups) {
+    if (G > 1) {
+        for (int jj = j;; jj += NW) {
+            if (b + G * jj >= ngroups) return -1;
+            const unsigned word = __builtin_amdgcn_readfirstlane(L.dead[(jj >> 5) & (DEADW - 1)]);
+            if (!((word >> (jj & 31)) & 1u)) return jj;
+        }
+    }
     const int w = j & (NW - 1);
     int m = j / NW;
-    int g = b + G * j; // global group of (w, m); one round of the workgroup's wavefronts further: + G * NW
-    const int gstep = G * NW;
-    if (g >= ngroups) return -1;
+    if (j >= ngroups) return -1; // (G == 1, b == 0: local group == global group)
     unsigned word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]);
     if (!((word >> (m & 31)) & 1u)) return j; // the common case while a trial is busy: the very next group is live
     for (;;) { // skip finished groups a word at a time
         const unsigned live = ~word >> (m & 31); // bit k: group m + k is live (zeros shifted in from the top = "not in this word")
         if (live) {
-            const int k = __builtin_ctz(live);
-            m += k; g += k * gstep;
-            return g >= ngroups ? -1 : w + NW * m;
+            m += __builtin_ctz(live);
+            return w + NW * m >= ngroups ? -1 : w + NW * m;
         }
-        const int k = 32 - (m & 31);
-        m += k; g += k * gstep;
-        if (g >= ngroups) return -1;
+        m = (m | 31) + 1;
+        if (w + NW * m >= ngroups) return -1;
         word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]);
     }
 }
@@ -314,7 +322,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
 
     if (!__any(busy || dirty)) {
         // nothing happens in this group; retire it for good once every UE in it has finished
-        if (jdead >= 0 && __all(i >= nUE || u.act == ACT_DONE) && lane == 0) dead_mark(L, jdead);
+        if (jdead >= 0 && __all(i >= nUE || u.act == ACT_DONE) && lane == 0) dead_mark(L, jdead, C.G);
         return;
     }
 
@@ -557,7 +565,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         const bool heavy = !lightc && !quiet;
         if (!__any(lightc || heavy)) {
             // nothing happens in this group; retire it for good once every UE in it has finished
-            if (__all(done) && lane == 0) dead_mark(L, j);
+            if (__all(done) && lane == 0) dead_mark(L, j, C.G);
             return;
         }
         if (lightc) { // Beta.c:245 + the txTime++ of Beta.c:346,358
