@@ -50,7 +50,8 @@ class PrachUeLog(C.Structure):
 
 class PrachTiming(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("total_ms", C.c_double),
-                ("launches", C.c_int32), ("workgroups", C.c_int32), ("updates", C.c_uint64)]
+                ("launches", C.c_int32), ("workgroups", C.c_int32), ("updates", C.c_uint64),
+                ("cluster_size", C.c_int32), ("resident_limit", C.c_int32), ("fallback_trials", C.c_int32), ("spin_timeouts", C.c_int32)]
 
 
 class PrachError(RuntimeError):
@@ -100,6 +101,7 @@ def lib():
         L.prach_result_file_name.argtypes = [C.POINTER(PrachCfg), C.c_int, C.c_char_p, C.c_size_t]
         L.prach_write_trial_files.argtypes = [C.POINTER(PrachCfg), C.POINTER(PrachResult), C.POINTER(PrachUeLog), C.c_double, C.c_char_p]
         L.prach_noma_activation_table.argtypes = [C.POINTER(PrachCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.prach_noma_activation_range.argtypes = [C.POINTER(PrachCfg), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.prach_format_noma_line.argtypes = [C.POINTER(PrachCfg), C.POINTER(PrachResult), C.c_char_p, C.c_size_t]
         L.prach_format_noma_line.restype = C.c_size_t
         L.prach_results_csv_accumulate.argtypes = [C.POINTER(C.c_double), C.c_char_p]
@@ -113,7 +115,7 @@ EXPORTS = ("prach_engine_create", "prach_engine_destroy", "prach_engine_set", "p
            "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_arrival_schedule", "prach_glibc_stream",
            "prach_strerror", "prach_format_logs", "prach_format_results", "prach_format_stdout",
            "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line",
-           "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream")
+           "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream", "prach_noma_activation_range")
 
 
 def make_cfg(nUE, variant=VARIANT_BETA_C, uniform=0, rng_mode=RNG_GLIBC, seed=0, stream_offset=0, **kw) -> PrachCfg:
@@ -155,15 +157,19 @@ class Engine:
 
     def run_trials(self, cfgs, want_logs=False):
         """Run the trials concurrently on the device. Returns (results, logs) — logs[k] is a ctypes
-        array of PrachUeLog or None."""
+        array of PrachUeLog or None.  want_logs: True (every trial), False, or the indices of the trials
+        whose per-UE log is wanted (the C ABI takes NULL for the others)."""
         n = len(cfgs)
         arr = (PrachCfg * n)(*cfgs)
         res = (PrachResult * n)()
         logs = [None] * n
         lp = None
         if want_logs:
-            logs = [(PrachUeLog * c.nUE)() for c in cfgs]
-            lp = (C.POINTER(PrachUeLog) * n)(*[C.cast(l, C.POINTER(PrachUeLog)) for l in logs])
+            which = range(n) if want_logs is True else sorted(set(int(k) for k in want_logs))
+            for k in which:
+                logs[k] = (PrachUeLog * cfgs[k].nUE)()
+            lp = (C.POINTER(PrachUeLog) * n)(*[C.cast(l, C.POINTER(PrachUeLog)) if l is not None else C.POINTER(PrachUeLog)()
+                                               for l in logs])
         rc = lib().prach_run_trials(self._h, arr, n, res, lp)
         if rc != OK:
             raise PrachError(rc, "(prach_run_trials)")

@@ -164,7 +164,7 @@ __device__ __forceinline__ long long wait_granule(const PRACH_G long long *p, un
     unsigned spins = 0;
     while (!granule_ok(g, tag)) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > SPIN_LIMIT) { *status_word = PRACH_ERR_INTERNAL; break; }
+        if (++spins > SPIN_LIMIT) { *status_word = PRACH_ERR_TIMEOUT; break; } // peer not resident? the engine reruns the trial
         g = ld_sc1_64(p);
     }
     return g;
@@ -738,7 +738,10 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fca
 template <bool GLIBC, bool H8>
 __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = blockIdx.x % nT, b = blockIdx.x / nT;
+    // the workgroups of a cluster are CONSECUTIVE blocks: in-order dispatch completes whole clusters even when not every
+    // block of the grid is resident at once (the engine keeps G x trials within the occupancy query's answer anyway)
+    const int T = blockIdx.x / G, b = blockIdx.x % G;
+    (void)nT;
     const TrialG P(params[T]);
     const CLds L = ccarve(smem, P.nP, GLIBC);
     const int tid = threadIdx.x;
@@ -1216,17 +1219,31 @@ size_t cluster_kernel_lds_bytes(int nP, bool glibc) {
     return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 15 * nP + QCAP + (glibc ? 4 * GSCAP : 0));
 }
 
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream) {
+using cluster_kernel_t = void (*)(const TrialDev *, int, int);
+static cluster_kernel_t pick_cluster_kernel(int rng_mode, int compact_records) {
     const bool glibc = rng_mode == PRACH_RNG_GLIBC;
-    const size_t lds = cluster_kernel_lds_bytes(maxP, glibc);
-    using kernel_t = void (*)(const TrialDev *, int, int);
     // compact_records: the 8 + 4 byte hot record (streaming regime: one workgroup per trial); else the 16-byte record
-    const kernel_t fn = glibc ? (compact_records ? cluster_kernel<true, true> : cluster_kernel<true, false>)
-                              : (compact_records ? cluster_kernel<false, true> : cluster_kernel<false, false>);
+    return glibc ? (compact_records ? cluster_kernel<true, true> : cluster_kernel<true, false>)
+                 : (compact_records ? cluster_kernel<false, true> : cluster_kernel<false, false>);
+}
+
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream) {
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, compact_records);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(fn, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
     return hipGetLastError();
+}
+
+// workgroups of this kernel (with its dynamic LDS) the runtime admits per CU: what a cooperative launch would be checked against
+int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int compact_records) {
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, compact_records);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;
+    return nb;
 }
 
 } // namespace prach

@@ -65,7 +65,6 @@ struct TrialDev {
     int evw, mbstride;           // events per mailbox, mailbox stride (ints)
     int binshift;                // grant selection: UE index >> binshift < 1024
     int *mbox;                   // [2][G][mbstride] write-through mailboxes
-    unsigned *bar;               // arrival counter (zeroed before every launch)
     int2 *cand;                  // early-leaver candidate scratch, nUE + 64*G entries
     int dense_pass;              // 1: every group through the full per-UE body (diagnostic option); 0: compacted pass
     int pipeline;                // 1: clusters run phase A of the next subframe during the exchange of the current one
@@ -85,6 +84,7 @@ size_t trial_kernel_lds_bytes(int nP);
 hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream);
 size_t cluster_kernel_lds_bytes(int nP, bool glibc);
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream);
+int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int compact_records); // occupancy query for the kernel and its dynamic LDS size
 constexpr int STREAM_CHUNK = 31 * 2048; // rand() outputs generated per wavefront (prach_stream.hip)
 hipError_t launch_glibc_stream(const unsigned *seeds, int *out, unsigned long long n, hipStream_t stream);
 extern "C" void prach_internal_glibc_seeds(uint32_t seed, uint64_t first, uint64_t nchunks, uint64_t chunk, uint32_t *out);
@@ -92,5 +92,6 @@ constexpr int CLUSTER_GLIBC_MAX_UE = 4096 * 64; // glibc mode on the cluster ker
 constexpr int CLUSTER_MAX_G = 64;
 size_t noma_kernel_lds_bytes(int nP);
 hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
+int noma_kernel_blocks_per_cu(int maxP);
 
 } // namespace prach

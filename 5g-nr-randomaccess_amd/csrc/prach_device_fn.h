@@ -81,7 +81,6 @@ struct TrialG {
     PRACH_G DevResult *out;
     int evw, mbstride, binshift;
     PRACH_G int *mbox;
-    PRACH_G unsigned *bar;
     PRACH_G v2i_t *cand;
     int dense_pass, pipeline;
     const PRACH_G int *n_pre0, *n_sector;
@@ -95,7 +94,7 @@ struct TrialG {
           fcnt((PRACH_G int *)d.fcnt), nd((PRACH_G unsigned *)d.nd), evbuf((PRACH_G v4i_t *)d.evbuf), evbuf2((PRACH_G v4i_t *)d.evbuf2),
           sidx((PRACH_G int *)d.sidx), sched((const PRACH_G int *)d.sched), stream((const PRACH_G int *)d.stream), logs((PRACH_G v4i_t *)d.logs),
           timers((PRACH_G int *)d.timers), out((PRACH_G DevResult *)d.out), evw(d.evw), mbstride(d.mbstride), binshift(d.binshift),
-          mbox((PRACH_G int *)d.mbox), bar((PRACH_G unsigned *)d.bar), cand((PRACH_G v2i_t *)d.cand), dense_pass(d.dense_pass), pipeline(d.pipeline),
+          mbox((PRACH_G int *)d.mbox), cand((PRACH_G v2i_t *)d.cand), dense_pass(d.dense_pass), pipeline(d.pipeline),
           n_pre0((const PRACH_G int *)d.n_pre0), n_sector((const PRACH_G int *)d.n_sector), n_gain((const PRACH_G double *)d.n_gain),
           n_lgain((const PRACH_G double *)d.n_lgain), n_nd0((const PRACH_G unsigned *)d.n_nd0) {}
 };

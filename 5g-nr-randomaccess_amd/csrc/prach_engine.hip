@@ -1,8 +1,8 @@
 // prach_engine.hip — host side of libprach_hip.so: the engine behind the C ABI in include/prach.h.
-// Owns the HIP stream, one device arena (grown on demand, never allocated per subframe), stages
-// the per-trial parameter blocks / arrival tables / draw streams, launches the trial kernel and
-// turns DevResult into prach_result.  There is NO CPU fallback: without a gfx950 device every
-// entry point that simulates returns PRACH_ERR_DEVICE.
+// Owns the HIP stream, one device arena and one pinned staging buffer (both grown on demand, nothing is
+// allocated per subframe or per trial), stages the per-trial parameter blocks / arrival tables / draw-stream
+// seeds of a whole launch with ONE copy, launches the trial kernels and turns DevResult into prach_result.
+// There is NO CPU fallback: without a gfx950 device every entry point that simulates returns PRACH_ERR_DEVICE.
 #include "prach_device.h"
 
 #include <algorithm>
@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits.h>
+#include <new>
+#include <thread>
 #include <vector>
 
 using namespace prach;
@@ -31,6 +33,8 @@ struct prach_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     char *arena = nullptr;
     size_t arena_cap = 0;
+    char *pinned = nullptr; // host staging mirror of the head of the arena (parameter blocks, arrival tables, stream seeds, results)
+    size_t pinned_cap = 0;
     prach_timing last{};
     int64_t opt_stream_factor = 0; // glibc: initial draws-per-UE budget override (0 = auto)
     int64_t opt_cluster = 0;       // workgroups per trial for the Philox cluster kernel (0 = auto)
@@ -38,8 +42,10 @@ struct prach_engine {
     int64_t opt_dense = 0;         // 1: cluster kernel without the compacted pass (diagnostic)
     int64_t opt_wide_records = 0;  // 1: 16-byte records also with one workgroup per trial (diagnostic)
     int64_t opt_pipeline = 1;      // 0: clusters do not run phase A ahead of the exchange (diagnostic)
-    int last_G = 0;
-    int num_cus = 256;            // co-residency budget of the cluster kernels: one 1024-thread workgroup per CU
+    int64_t opt_resident = 0;      // test hook: pretend only this many workgroups can be co-resident (0 = ask the runtime)
+    int64_t opt_host_threads = 0;  // host threads for the NOMA.c activation tables (0 = all cores)
+    int64_t opt_lds_records = 1;   // 0: clusters keep their UE records in global memory (diagnostic)
+    int num_cus = 256;
 };
 
 namespace {
@@ -47,44 +53,79 @@ namespace {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct TrialLayout {
-    size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, bar, cand, end;
+    size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, cand;
     size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0;
     size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
     int evw, mbstride;
 };
 
-TrialLayout layout_trial(const prach_cfg &c, size_t base, bool want_logs, size_t stream_len, int G) {
-    TrialLayout L{};
-    size_t o = base;
+// Arena of one launch:
+//   [ TrialDev[m] | arrival tables | glibc stream seeds ]   staged region: built in pinned host memory, ONE copy
+//   [ DevResult[m] | mailboxes ]                             zeroed region: ONE memset per launch (tags: 0 never equals t+1);
+//                                                            the DevResult block also comes back with ONE copy
+//   [ per-trial arrays ]                                     records, cold fields, scratch of the kernel that runs
+struct LaunchLayout {
+    std::vector<TrialLayout> t;
+    size_t staged_end = 0, zero_begin = 0, zero_end = 0, out0 = 0, end = 0;
+};
+
+size_t mbox_bytes(const prach_cfg &c, int G, int &evw, int &mbstride) {
+    evw = 0; mbstride = 0;
+    if (G <= 0) return 0;
     const size_t n = (size_t)c.nUE;
+    evw = G == 1 ? 4096 : 512;
+    const size_t lgroups = ((n + 63) / 64 + (size_t)G - 1) / (size_t)G;
+    mbstride = (int)align_up((size_t)2 * (1 + c.nPreamble + evw + (lgroups + 1) / 2), 4); // 8-byte granules: header, buckets, events, (glibc) group draw counts
+    if (c.variant == PRACH_VARIANT_NOMA_C) mbstride = (int)align_up((size_t)2 * (1 + 6 * c.nPreamble), 4); // header + 6 x nP bins
+    if (G == 1) return 256; // one workgroup per trial exchanges nothing
+    return 4 * (size_t)2 * G * mbstride;
+}
+
+// stream_len[k]: glibc draw-stream window of trial k (0 in Philox mode); G: workgroups per trial (0 = trial_kernel)
+LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_ue_log *const *ue_logs, const std::vector<size_t> &stream_len, int G) {
+    LaunchLayout L;
+    L.t.resize(m);
+    size_t o = align_up(sizeof(TrialDev) * (size_t)m, 256);
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
-    L.rec = take(16 * n);
-    L.ptc = take(4 * n); L.ftt = take(4 * n); L.stt = take(4 * n); L.fcnt = take(4 * n); L.nd = take(4 * n);
-    L.evbuf = take(sizeof(Event) * n); L.evbuf2 = take(sizeof(Event) * n);
-    L.sidx = take(4 * (n + 256));
-    L.sched_len = (size_t)(prach_max_time(&c) / c.accessTime + 2);
-    L.sched = take(4 * L.sched_len);
-    L.stream_len = stream_len;
-    L.stream = take(4 * (stream_len + 2));
-    L.nchunks = (stream_len + STREAM_CHUNK - 1) / STREAM_CHUNK;
-    L.seeds = take(4 * 31 * (L.nchunks + 1));
-    L.logs = want_logs ? take(sizeof(prach_ue_log) * n) : 0;
-    L.timers = take(4 * n);
-    L.out = take(sizeof(DevResult));
-    L.evw = 0; L.mbstride = 0; L.mbox = L.bar = L.cand = 0;
-    if (G > 0) { // cluster kernel: mailboxes, arrival counter, early-leaver candidate scratch
-        L.evw = G == 1 ? 4096 : 512;
-        const size_t lgroups = ((n + 63) / 64 + (size_t)G - 1) / (size_t)G;
-        L.mbstride = (int)align_up((size_t)2 * (1 + c.nPreamble + L.evw + (lgroups + 1) / 2), 4); // 8-byte granules: header, buckets, events, (glibc) group draw counts
-        if (c.variant == PRACH_VARIANT_NOMA_C) L.mbstride = (int)align_up((size_t)2 * (1 + 6 * c.nPreamble), 4); // header + 6 x nP bins
-        L.mbox = take(4 * (size_t)2 * G * L.mbstride);
-        L.bar = take(256);
-        L.cand = take(8 * (n + 64 * (size_t)G + 64));
+    for (int k = 0; k < m; k++) { // staged region
+        const prach_cfg &c = cfgs[idx[k]];
+        TrialLayout &T = L.t[k];
+        T.sched_len = (size_t)(prach_max_time(&c) / c.accessTime + 2);
+        T.sched = take(4 * T.sched_len);
+        T.stream_len = stream_len[k];
+        T.nchunks = (T.stream_len + STREAM_CHUNK - 1) / STREAM_CHUNK;
+        T.seeds = T.stream_len ? take(4 * 31 * (T.nchunks + 1)) : 0;
     }
-    L.n_pre0 = L.n_sector = L.n_gain = L.n_lgain = L.n_nd0 = 0;
-    if (c.variant == PRACH_VARIANT_NOMA_C) {
-        L.n_pre0 = take(4 * n); L.n_sector = take(4 * n); L.n_gain = take(8 * n); L.n_lgain = take(8 * n); L.n_nd0 = take(4 * n);
+    L.staged_end = o;
+    L.zero_begin = o;
+    L.out0 = take(sizeof(DevResult) * (size_t)m);
+    for (int k = 0; k < m; k++) {
+        L.t[k].out = L.out0 + sizeof(DevResult) * (size_t)k;
+        const size_t mb = mbox_bytes(cfgs[idx[k]], G, L.t[k].evw, L.t[k].mbstride);
+        L.t[k].mbox = mb ? take(mb) : 0;
+    }
+    L.zero_end = o;
+    for (int k = 0; k < m; k++) {
+        const prach_cfg &c = cfgs[idx[k]];
+        TrialLayout &T = L.t[k];
+        const size_t n = (size_t)c.nUE;
+        T.rec = take(16 * n);
+        T.ptc = take(4 * n); T.ftt = take(4 * n); T.stt = take(4 * n); T.fcnt = take(4 * n); T.nd = take(4 * n);
+        T.evbuf = T.evbuf2 = T.sidx = T.cand = 0;
+        if (G == 0) { // trial_kernel only: event / singleton scratch without a per-subframe capacity
+            T.evbuf = take(sizeof(Event) * n); T.evbuf2 = take(sizeof(Event) * n);
+            T.sidx = take(4 * (n + 256));
+        } else if (c.variant != PRACH_VARIANT_NOMA_C) {
+            T.cand = take(8 * (n + 64 * (size_t)G + 64)); // cluster kernel: early-leaver candidates
+        }
+        T.stream = T.stream_len ? take(4 * (T.stream_len + 2)) : 0;
+        T.logs = (ue_logs && ue_logs[idx[k]]) ? take(sizeof(prach_ue_log) * n) : 0;
+        T.timers = take(4 * n);
+        T.n_pre0 = T.n_sector = T.n_gain = T.n_lgain = T.n_nd0 = 0;
+        if (c.variant == PRACH_VARIANT_NOMA_C) {
+            T.n_pre0 = take(4 * n); T.n_sector = take(4 * n); T.n_gain = take(8 * n); T.n_lgain = take(8 * n); T.n_nd0 = take(4 * n);
+        }
     }
     L.end = o;
     return L;
@@ -97,13 +138,43 @@ uint64_t stream_budget(const prach_cfg &c, int attempt, int64_t factor) {
     return b << (2 * attempt);
 }
 
+int ensure_arena(prach_engine *e, size_t need) {
+    if (need <= e->arena_cap) return PRACH_OK;
+    if (e->arena) HIPCHK(hipFree(e->arena));
+    e->arena = nullptr;
+    e->arena_cap = 0;
+    const size_t want = need + (need >> 3);
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->arena), want));
+    e->arena_cap = want;
+    return PRACH_OK;
+}
+int ensure_pinned(prach_engine *e, size_t need) {
+    if (need <= e->pinned_cap) return PRACH_OK;
+    if (e->pinned) HIPCHK(hipHostFree(e->pinned));
+    e->pinned = nullptr;
+    e->pinned_cap = 0;
+    const size_t want = need + (need >> 2) + 4096;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&e->pinned), want, hipHostMallocDefault));
+    e->pinned_cap = want;
+    return PRACH_OK;
+}
+
+int host_threads(const prach_engine *e) {
+    int n = e->opt_host_threads > 0 ? (int)e->opt_host_threads : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(n, 64));
+}
+
+// Workgroups of the given cluster launch that can be resident at once on this device: the runtime's occupancy answer for
+// the kernel and its dynamic LDS size, times the CU count (MI355X_MICROARCH.md "Residency and cooperative launch": a
+// plain launch has the same residency as a cooperative one; the query is what a cooperative launch would check).
+int resident_workgroups(const prach_engine *e, int per_cu) {
+    if (e->opt_resident > 0) return (int)e->opt_resident;
+    return std::max(1, per_cu) * e->num_cus;
+}
+
 } // namespace
 
-extern "C" {
-
-int prach_engine_create(int device, prach_engine **out) {
-    if (!out) return PRACH_ERR_ARG;
-    *out = nullptr;
+static int engine_create_impl(int device, prach_engine **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         std::fprintf(stderr, "[prach] no HIP device: libprach_hip needs an MI355X (gfx950); there is no CPU fallback\n");
@@ -117,61 +188,18 @@ int prach_engine_create(int device, prach_engine **out) {
         std::fprintf(stderr, "[prach] device %d is %s; this library is built for gfx950 only\n", device, prop.gcnArchName);
         return PRACH_ERR_DEVICE;
     }
-    prach_engine *e = new prach_engine();
+    prach_engine *e = new (std::nothrow) prach_engine();
+    if (!e) return PRACH_ERR_DEVICE;
     e->device = device;
     e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&e->ev0));
-    HIPCHK(hipEventCreate(&e->ev1));
+    int rc = [&]() -> int {
+        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&e->ev0));
+        HIPCHK(hipEventCreate(&e->ev1));
+        return PRACH_OK;
+    }();
+    if (rc != PRACH_OK) { prach_engine_destroy(e); return rc; } // (nothing half-built is leaked)
     *out = e;
-    return PRACH_OK;
-}
-
-void prach_engine_destroy(prach_engine *e) {
-    if (!e) return;
-    (void)hipSetDevice(e->device);
-    if (e->arena) (void)hipFree(e->arena);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
-    delete e;
-}
-
-int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
-    if (!e || !key) return PRACH_ERR_ARG;
-    if (std::strcmp(key, "stream_factor") == 0) { e->opt_stream_factor = value; return PRACH_OK; }
-    if (std::strcmp(key, "cluster") == 0) { if (value < 0 || value > CLUSTER_MAX_G) return PRACH_ERR_ARG; e->opt_cluster = value; return PRACH_OK; }
-    if (std::strcmp(key, "legacy") == 0) { e->opt_legacy = value != 0; return PRACH_OK; }
-    if (std::strcmp(key, "dense") == 0) { e->opt_dense = value != 0; return PRACH_OK; }
-    if (std::strcmp(key, "wide_records") == 0) { e->opt_wide_records = value != 0; return PRACH_OK; }
-    if (std::strcmp(key, "pipeline") == 0) { e->opt_pipeline = value != 0; return PRACH_OK; }
-    return PRACH_ERR_ARG;
-}
-
-int prach_device_glibc_stream(prach_engine *e, uint32_t seed, uint64_t first, uint64_t n, int32_t *out) {
-    if (!e || !out || n == 0) return PRACH_ERR_ARG;
-    HIPCHK(hipSetDevice(e->device));
-    const size_t nchunks = (n + STREAM_CHUNK - 1) / STREAM_CHUNK;
-    const size_t need = align_up(4 * 31 * nchunks, 256) + 4 * (n + 2);
-    if (need > e->arena_cap) {
-        if (e->arena) HIPCHK(hipFree(e->arena));
-        e->arena = nullptr; e->arena_cap = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->arena), need));
-        e->arena_cap = need;
-    }
-    std::vector<uint32_t> seeds(31 * nchunks);
-    prach_internal_glibc_seeds(seed, first, nchunks, STREAM_CHUNK, seeds.data());
-    HIPCHK(hipMemcpy(e->arena, seeds.data(), 4 * 31 * nchunks, hipMemcpyHostToDevice));
-    int *dout = reinterpret_cast<int *>(e->arena + align_up(4 * 31 * nchunks, 256));
-    HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(e->arena), dout, n, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
-    return PRACH_OK;
-}
-
-int prach_last_timing(const prach_engine *e, prach_timing *out) {
-    if (!e || !out) return PRACH_ERR_ARG;
-    *out = e->last;
     return PRACH_OK;
 }
 
@@ -179,34 +207,27 @@ int prach_last_timing(const prach_engine *e, prach_timing *out) {
 static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, prach_result *results,
                      prach_ue_log *const *ue_logs, int attempt, int G, double &kernel_ms, double &upload_ms) {
     const int rng_mode = cfgs[idx[0]].rng_mode;
-    std::vector<TrialLayout> lay(m);
-    size_t o = align_up(sizeof(TrialDev) * (size_t)m, 256);
+    const bool noma = cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C;
+    std::vector<size_t> slen(m, 0);
     int maxP = 1;
     for (int k = 0; k < m; k++) {
         const prach_cfg &c = cfgs[idx[k]];
-        const bool wl = ue_logs && ue_logs[idx[k]];
-        const size_t sl = rng_mode == PRACH_RNG_GLIBC ? (size_t)stream_budget(c, attempt, e->opt_stream_factor) : 0;
-        lay[k] = layout_trial(c, o, wl, sl, G);
-        o = lay[k].end;
+        if (rng_mode == PRACH_RNG_GLIBC) slen[k] = (size_t)stream_budget(c, attempt, e->opt_stream_factor);
         if (c.nPreamble > maxP) maxP = c.nPreamble;
     }
-    if (o > e->arena_cap) {
-        if (e->arena) HIPCHK(hipFree(e->arena));
-        e->arena = nullptr;
-        e->arena_cap = 0;
-        const size_t want = o + (o >> 3);
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->arena), want));
-        e->arena_cap = want;
-    }
+    const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G);
+    { int rc = ensure_arena(e, LL.end); if (rc != PRACH_OK) return rc; }
+    { int rc = ensure_pinned(e, std::max(LL.staged_end, sizeof(DevResult) * (size_t)m)); if (rc != PRACH_OK) return rc; }
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<TrialDev> td(m);
-    std::vector<int32_t> sched;
-    std::vector<uint32_t> seeds;
+    char *const A = e->arena;
+    char *const H = e->pinned;
+    TrialDev *const td = reinterpret_cast<TrialDev *>(H);
     std::vector<int32_t> nAccess(m, 0);
     for (int k = 0; k < m; k++) {
         const prach_cfg &c = cfgs[idx[k]];
-        const TrialLayout &L = lay[k];
+        const TrialLayout &L = LL.t[k];
         TrialDev &d = td[k];
+        std::memset(&d, 0, sizeof(d));
         d.variant = c.variant; d.uniform = c.uniform; d.nUE = c.nUE; d.nP = c.nPreamble; d.backoff = c.backoff;
         d.nGrantUL = c.nGrantUL; d.maxRarWindow = c.maxRarWindow; d.maxMsg2 = c.maxMsg2TxCount; d.aT = c.accessTime;
         d.rng_mode = c.rng_mode; d.maxTime = prach_max_time(&c);
@@ -215,60 +236,79 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.stream_len = L.stream_len;
         d.dense_pass = e->opt_dense ? 1 : 0;
         d.pipeline = e->opt_pipeline ? 1 : 0;
-        char *A = e->arena;
         d.rec = reinterpret_cast<int4 *>(A + L.rec);
         d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);
         d.stt = reinterpret_cast<int *>(A + L.stt); d.fcnt = reinterpret_cast<int *>(A + L.fcnt);
         d.nd = reinterpret_cast<unsigned *>(A + L.nd);
-        d.evbuf = reinterpret_cast<Event *>(A + L.evbuf); d.evbuf2 = reinterpret_cast<Event *>(A + L.evbuf2);
-        d.sidx = reinterpret_cast<int *>(A + L.sidx);
+        d.evbuf = L.evbuf ? reinterpret_cast<Event *>(A + L.evbuf) : nullptr;
+        d.evbuf2 = L.evbuf2 ? reinterpret_cast<Event *>(A + L.evbuf2) : nullptr;
+        d.sidx = L.sidx ? reinterpret_cast<int *>(A + L.sidx) : nullptr;
         d.sched = reinterpret_cast<const int *>(A + L.sched);
-        d.stream = reinterpret_cast<const int *>(A + L.stream);
+        d.stream = L.stream ? reinterpret_cast<const int *>(A + L.stream) : nullptr;
         d.logs = L.logs ? reinterpret_cast<prach_ue_log *>(A + L.logs) : nullptr;
         d.timers = reinterpret_cast<int *>(A + L.timers);
         d.out = reinterpret_cast<DevResult *>(A + L.out);
         d.evw = L.evw; d.mbstride = L.mbstride;
         d.binshift = 0;
         while (((c.nUE - 1) >> d.binshift) >= 1024) d.binshift++;
-        d.mbox = G > 0 ? reinterpret_cast<int *>(A + L.mbox) : nullptr;
-        d.bar = G > 0 ? reinterpret_cast<unsigned *>(A + L.bar) : nullptr;
-        d.cand = G > 0 ? reinterpret_cast<int2 *>(A + L.cand) : nullptr;
-        if (G > 0) { // words polled / accumulated in-kernel are zeroed before EVERY launch
-            HIPCHK(hipMemsetAsync(A + L.out, 0, sizeof(DevResult), e->stream));
-            HIPCHK(hipMemsetAsync(A + L.bar, 0, 256, e->stream));
-            HIPCHK(hipMemsetAsync(A + L.mbox, 0, 4 * (size_t)2 * G * L.mbstride, e->stream)); // tags: 0 never equals t+1
-        }
-        sched.assign(L.sched_len, c.nUE);
-        prach_arrival_schedule(&c, sched.data(), (int)L.sched_len, &nAccess[k]);
-        HIPCHK(hipMemcpyAsync(A + L.sched, sched.data(), 4 * L.sched_len, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream)); // staging vector is reused
-        d.n_pre0 = d.n_sector = nullptr; d.n_gain = d.n_lgain = nullptr; d.n_nd0 = nullptr;
-        if (c.variant == PRACH_VARIANT_NOMA_C) { // activeUE's per-UE attributes (double-precision libm work): host, once per trial
-            const size_t nn = (size_t)c.nUE;
-            std::vector<int32_t> pre0(nn), sec(nn);
-            std::vector<double> gn(nn), lg(nn);
-            std::vector<uint32_t> nd0(nn);
-            int trc = prach_noma_activation_table(&c, pre0.data(), sec.data(), gn.data(), lg.data(), nd0.data());
-            if (trc != PRACH_OK) return trc;
-            HIPCHK(hipMemcpy(A + L.n_pre0, pre0.data(), 4 * nn, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(A + L.n_sector, sec.data(), 4 * nn, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(A + L.n_gain, gn.data(), 8 * nn, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(A + L.n_lgain, lg.data(), 8 * nn, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(A + L.n_nd0, nd0.data(), 4 * nn, hipMemcpyHostToDevice));
+        d.mbox = L.mbox ? reinterpret_cast<int *>(A + L.mbox) : nullptr;
+        d.cand = L.cand ? reinterpret_cast<int2 *>(A + L.cand) : nullptr;
+        int32_t *sched = reinterpret_cast<int32_t *>(H + L.sched);
+        for (size_t s = 0; s < L.sched_len; s++) sched[s] = c.nUE;
+        prach_arrival_schedule(&c, sched, (int)L.sched_len, &nAccess[k]);
+        if (rng_mode == PRACH_RNG_GLIBC)
+            // the reference's rand() stream window [stream_offset, +stream_len): the host only jumps ahead (31-word window
+            // per chunk, cached matrix powers); the values themselves are generated on the device inside the timed region
+            prach_internal_glibc_seeds((uint32_t)c.seed, c.stream_offset, L.nchunks, STREAM_CHUNK, reinterpret_cast<uint32_t *>(H + L.seeds));
+        if (noma) {
             d.n_pre0 = reinterpret_cast<const int *>(A + L.n_pre0); d.n_sector = reinterpret_cast<const int *>(A + L.n_sector);
             d.n_gain = reinterpret_cast<const double *>(A + L.n_gain); d.n_lgain = reinterpret_cast<const double *>(A + L.n_lgain);
             d.n_nd0 = reinterpret_cast<const unsigned *>(A + L.n_nd0);
         }
-        if (rng_mode == PRACH_RNG_GLIBC) {
-            // the reference's rand() stream window [stream_offset, +stream_len): the host only jumps ahead (31-word window
-            // per chunk, cached matrix powers); the values themselves are generated on the device inside the timed region
-            seeds.resize(31 * (L.nchunks + 1));
-            prach_internal_glibc_seeds((uint32_t)c.seed, c.stream_offset, L.nchunks, STREAM_CHUNK, seeds.data());
-            HIPCHK(hipMemcpyAsync(A + L.seeds, seeds.data(), 4 * 31 * L.nchunks, hipMemcpyHostToDevice, e->stream));
-            HIPCHK(hipStreamSynchronize(e->stream));
-        }
     }
-    HIPCHK(hipMemcpyAsync(e->arena, td.data(), sizeof(TrialDev) * (size_t)m, hipMemcpyHostToDevice, e->stream));
+    if (noma) {
+        // activeUE's per-UE attributes (NOMA.c:131-192: double-precision libm work, once per UE): built on the host with the
+        // libm the reference links, UE ranges of all trials dealt to all host cores, then copied trial by trial
+        const int nth = host_threads(e);
+        struct Tab { std::vector<int32_t> pre0, sec; std::vector<double> gn, lg; std::vector<uint32_t> nd0; };
+        std::vector<Tab> tabs(m);
+        struct Job { int k, lo, hi; };
+        std::vector<Job> jobs;
+        for (int k = 0; k < m; k++) {
+            const int n = cfgs[idx[k]].nUE;
+            tabs[k].pre0.resize(n); tabs[k].sec.resize(n); tabs[k].gn.resize(n); tabs[k].lg.resize(n); tabs[k].nd0.resize(n);
+            const int step = std::max(2048, (n + nth - 1) / nth);
+            for (int lo = 0; lo < n; lo += step) jobs.push_back({k, lo, std::min(n, lo + step)});
+        }
+        std::vector<int> jrc(jobs.size(), PRACH_OK);
+        auto work = [&](int tix) {
+            for (size_t j = (size_t)tix; j < jobs.size(); j += (size_t)nth) {
+                const Job &J = jobs[j];
+                Tab &T = tabs[J.k];
+                jrc[j] = prach_noma_activation_range(&cfgs[idx[J.k]], J.lo, J.hi, T.pre0.data() + J.lo, T.sec.data() + J.lo, T.gn.data() + J.lo,
+                                                     T.lg.data() + J.lo, T.nd0.data() + J.lo);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int tix = 1; tix < nth; tix++) th.emplace_back(work, tix);
+        work(0);
+        for (auto &x : th) x.join();
+        for (int r : jrc) if (r != PRACH_OK) return r;
+        for (int k = 0; k < m; k++) {
+            const size_t nn = (size_t)cfgs[idx[k]].nUE;
+            const TrialLayout &L = LL.t[k];
+            HIPCHK(hipMemcpyAsync(A + L.n_pre0, tabs[k].pre0.data(), 4 * nn, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(A + L.n_sector, tabs[k].sec.data(), 4 * nn, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(A + L.n_gain, tabs[k].gn.data(), 8 * nn, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(A + L.n_lgain, tabs[k].lg.data(), 8 * nn, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(A + L.n_nd0, tabs[k].nd0.data(), 4 * nn, hipMemcpyHostToDevice, e->stream));
+        }
+        HIPCHK(hipStreamSynchronize(e->stream)); // (the tables are pageable host memory that goes away)
+    }
+    // ONE copy stages every parameter block, arrival table and stream seed of the launch; ONE memset zeroes everything the
+    // kernels accumulate into or poll (DevResult blocks; mailbox tags: 0 never equals t + 1)
+    HIPCHK(hipMemcpyAsync(A, H, LL.staged_end, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(A + LL.zero_begin, 0, LL.zero_end - LL.zero_begin, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     auto t1 = std::chrono::steady_clock::now();
     upload_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -276,9 +316,9 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     HIPCHK(hipEventRecord(e->ev0, e->stream));
     if (rng_mode == PRACH_RNG_GLIBC)
         for (int k = 0; k < m; k++)
-            HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(e->arena + lay[k].seeds), reinterpret_cast<int *>(e->arena + lay[k].stream),
-                                       (unsigned long long)lay[k].stream_len, e->stream));
-    if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, e->stream));
+            HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(A + LL.t[k].seeds), reinterpret_cast<int *>(A + LL.t[k].stream),
+                                       (unsigned long long)LL.t[k].stream_len, e->stream));
+    if (noma) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, e->stream));
     else if (G > 0) {
         // one workgroup per trial = the streaming regime: 8 + 4 byte hot records, if every subframe number of every trial of
         // the launch fits 16 bits (txTime <= t + 59 + backoff + accessTime)
@@ -287,24 +327,25 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             const prach_cfg &c = cfgs[idx[k]];
             compact = (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 64 < 63000;
         }
-        HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, G, maxP, rng_mode, compact ? 1 : 0, e->stream));
+        HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, compact ? 1 : 0, e->stream));
     }
-    else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(e->arena), m, rng_mode, maxP, e->stream));
+    else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(A), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
+    HIPCHK(hipMemcpyAsync(H, A + LL.out0, sizeof(DevResult) * (size_t)m, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     kernel_ms += ms;
     e->last.launches++;
     e->last.workgroups = m * (G > 0 ? G : 1);
-    e->last_G = G;
+    e->last.cluster_size = G;
 
+    const DevResult *const drs = reinterpret_cast<const DevResult *>(H);
     std::vector<int32_t> timers;
     for (int k = 0; k < m; k++) {
         const prach_cfg &c = cfgs[idx[k]];
-        const TrialLayout &L = lay[k];
-        DevResult dr;
-        HIPCHK(hipMemcpy(&dr, e->arena + L.out, sizeof(dr), hipMemcpyDeviceToHost));
+        const TrialLayout &L = LL.t[k];
+        const DevResult &dr = drs[k];
         prach_result &r = results[idx[k]];
         std::memset(&r, 0, sizeof(r));
         r.status = dr.status;
@@ -339,20 +380,33 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             r.totalDelay = (float)dr.sumTimer;
         } else {
             timers.resize((size_t)c.nUE);
-            HIPCHK(hipMemcpy(timers.data(), e->arena + L.timers, 4 * (size_t)c.nUE, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(timers.data(), A + L.timers, 4 * (size_t)c.nUE, hipMemcpyDeviceToHost));
             float td_ = 0;
             for (int i = 0; i < c.nUE; i++)
                 if (timers[i] != INT_MIN) td_ += (float)timers[i];
             r.totalDelay = td_;
         }
         if (L.logs)
-            HIPCHK(hipMemcpy(ue_logs[idx[k]], e->arena + L.logs, sizeof(prach_ue_log) * (size_t)c.nUE, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(ue_logs[idx[k]], A + L.logs, sizeof(prach_ue_log) * (size_t)c.nUE, hipMemcpyDeviceToHost));
     }
     return PRACH_OK;
 }
 
-int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result *results, prach_ue_log *const *ue_logs) {
-    if (!e || !cfgs || !results || n <= 0) return PRACH_ERR_ARG;
+// A trial that a cluster launch could not finish — a per-subframe LDS capacity exceeded (PRACH_ERR_INTERNAL) or a workgroup
+// that waited too long for a peer (PRACH_ERR_TIMEOUT: the cluster's workgroups were not all resident, e.g. another process
+// holds CUs) — is rerun, exactly, on a kernel that needs neither.  Never silently: counted in prach_timing and reported.
+static void note_fallback(prach_engine *e, const char *what, size_t ntrials, size_t ntimeouts, int G) {
+    e->last.fallback_trials += (int32_t)ntrials;
+    e->last.spin_timeouts += (int32_t)ntimeouts;
+    std::fprintf(stderr, "[prach] %zu trial(s) of a %d-workgroup cluster launch are rerun on %s (%zu exceeded a per-subframe capacity, %zu timed out "
+                         "waiting for a peer workgroup: cluster not co-resident?)\n", ntrials, G, what, ntrials - ntimeouts, ntimeouts);
+}
+
+static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_result *results, prach_ue_log *const *ue_logs) {
+    for (int k = 0; k < n; k++) { // nothing is left uninitialised on an early error return
+        std::memset(&results[k], 0, sizeof(results[k]));
+        results[k].status = PRACH_ERR_INTERNAL;
+    }
     for (int k = 0; k < n; k++) {
         int v = prach_cfg_validate(&cfgs[k]);
         if (v != PRACH_OK) return v;
@@ -368,17 +422,31 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
         for (int k = 0; k < n; k++)
             if (cfgs[k].variant == PRACH_VARIANT_NOMA_C) idx.push_back(k);
         if (!idx.empty()) {
-            int minGroups = INT_MAX;
+            int minGroups = INT_MAX, maxP = 1;
             bool small = true;
-            for (int k : idx) { minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64); small = small && cfgs[k].nUE < (1 << 20) - 1; }
+            for (int k : idx) {
+                minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
+                small = small && cfgs[k].nUE < (1 << 20) - 1;
+                maxP = std::max(maxP, cfgs[k].nPreamble);
+            }
             int G = (int)e->opt_cluster;
-            const size_t resident = (size_t)e->num_cus * 3 / 4;
+            const size_t resident = (size_t)resident_workgroups(e, noma_kernel_blocks_per_cu(maxP));
+            e->last.resident_limit = (int32_t)resident;
             // (measured at nUE = 100 000: 23.2 ms with 16 workgroups, 24.3 with 32, 26.6 with 8: 6 x nPreamble bins per mailbox)
-            if (G <= 0) { G = 1; while (G * 2 <= 16 && (size_t)G * 2 * idx.size() <= resident / 2 + resident / 6 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
+            if (G <= 0) { G = 1; while (G * 2 <= 16 && (size_t)G * 2 * idx.size() <= resident / 2 && G * 2 <= std::max(1, minGroups / 16)) G *= 2; }
             while (G > 1 && (size_t)G * idx.size() > resident) G /= 2;
             if (!small) G = 1; // 20-bit granule fields
             int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, G, kernel_ms, upload_ms);
             if (rc != PRACH_OK) return rc;
+            std::vector<int> again;
+            size_t nto = 0;
+            for (int k : idx)
+                if (results[k].status == PRACH_ERR_TIMEOUT || results[k].status == PRACH_ERR_INTERNAL) { again.push_back(k); nto += results[k].status == PRACH_ERR_TIMEOUT; }
+            if (!again.empty() && G > 1) { // one workgroup per trial waits for nobody
+                note_fallback(e, "noma_kernel with one workgroup per trial", again.size(), nto, G);
+                rc = run_group(e, cfgs, again.data(), (int)again.size(), results, ue_logs, 0, 1, kernel_ms, upload_ms);
+                if (rc != PRACH_OK) return rc;
+            }
         }
     }
     for (int mode = 0; mode < 2; mode++) {
@@ -393,21 +461,24 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
             return work(a) > work(b);
         });
         bool cluster_ok = !e->opt_legacy;
+        int maxP = 1;
         for (int k : idx) {
             cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
-
             if (mode == PRACH_RNG_GLIBC) cluster_ok = cluster_ok && cfgs[k].nUE <= CLUSTER_GLIBC_MAX_UE;
+            maxP = std::max(maxP, cfgs[k].nPreamble);
         }
         if (cluster_ok) {
-            // production path: cluster kernel, G workgroups per trial (all clusters must be co-resident:
-            // at most one 1024-thread workgroup per CU)
+            // production path: cluster kernel, G workgroups per trial.  The workgroups of a cluster wait for each other, so
+            // every cluster of the launch must be resident: G x trials <= what the occupancy query admits for this kernel
+            // and LDS size (members of a cluster are consecutive workgroups: in-order dispatch completes whole clusters)
             int minGroups = INT_MAX;
             for (int k : idx) minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
             int G = (int)e->opt_cluster;
-            const size_t resident = (size_t)e->num_cus * 3 / 4; // every cluster must be co-resident: <= one workgroup per CU, with margin
+            const size_t resident = (size_t)resident_workgroups(e, cluster_kernel_blocks_per_cu(maxP, mode, 0));
+            e->last.resident_limit = (int32_t)resident;
             if (G <= 0) {
                 G = 1;
-                while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 + resident / 6 && G * 2 <= std::max(1, minGroups / 16)) G *= 2;
+                while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 && G * 2 <= std::max(1, minGroups / 16)) G *= 2;
                 // Uniform arrivals over 60 000 subframes (Beta.c:92-95): only nUE / 60 000 arrivals per subframe, a UE lives some
                 // tens of subframes, finished groups are skipped 32 at a time — the live band is a few groups and one workgroup
                 // steps through a subframe faster than a cluster exchanges (nUE = 100 000: 5.1 vs 6.2 us per subframe)
@@ -417,6 +488,7 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
             }
             while (G > 1 && (size_t)G * idx.size() > resident) G /= 2;
             std::vector<int> todo = idx, fallback;
+            size_t nto = 0;
             for (int attempt = 0; !todo.empty(); attempt++) {
                 if (attempt > 6) return PRACH_ERR_STREAM;
                 int rc = run_group(e, cfgs, todo.data(), (int)todo.size(), results, ue_logs, attempt, G, kernel_ms, upload_ms);
@@ -424,12 +496,16 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
                 std::vector<int> again;
                 for (int k : todo) {
                     if (results[k].status == PRACH_ERR_STREAM) again.push_back(k);         // glibc: draw-stream window ran out: larger one
-                    else if (results[k].status == PRACH_ERR_INTERNAL) fallback.push_back(k); // a per-subframe capacity was exceeded:
-                }                                                                              // exact rerun on trial_kernel
+                    else if (results[k].status == PRACH_ERR_INTERNAL || results[k].status == PRACH_ERR_TIMEOUT) {
+                        fallback.push_back(k);
+                        nto += results[k].status == PRACH_ERR_TIMEOUT;
+                    }
+                }
                 todo.swap(again);
             }
             idx.swap(fallback);
             if (idx.empty()) continue;
+            note_fallback(e, "trial_kernel (one workgroup per trial, no per-subframe capacity)", idx.size(), nto, G);
         }
         int attempt = 0;
         while (!idx.empty()) {
@@ -453,6 +529,75 @@ int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result
     e->last.updates = upd;
     e->last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return worst;
+}
+
+// C++ exceptions (std::bad_alloc from the staging vectors) never cross the C boundary
+#define PRACH_GUARD(body)                                                                              \
+    try { body } catch (const std::bad_alloc &) {                                                       \
+        std::fprintf(stderr, "[prach] out of host memory\n");                                          \
+        return PRACH_ERR_DEVICE;                                                                       \
+    } catch (...) { return PRACH_ERR_INTERNAL; }
+
+extern "C" {
+
+int prach_engine_create(int device, prach_engine **out) {
+    if (!out) return PRACH_ERR_ARG;
+    *out = nullptr;
+    PRACH_GUARD(return engine_create_impl(device, out);)
+}
+
+void prach_engine_destroy(prach_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->arena) (void)hipFree(e->arena);
+    if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
+    if (!e || !key) return PRACH_ERR_ARG;
+    if (std::strcmp(key, "stream_factor") == 0) { e->opt_stream_factor = value; return PRACH_OK; }
+    if (std::strcmp(key, "cluster") == 0) { if (value < 0 || value > CLUSTER_MAX_G) return PRACH_ERR_ARG; e->opt_cluster = value; return PRACH_OK; }
+    if (std::strcmp(key, "legacy") == 0) { e->opt_legacy = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "dense") == 0) { e->opt_dense = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "wide_records") == 0) { e->opt_wide_records = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "pipeline") == 0) { e->opt_pipeline = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "resident") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_resident = value; return PRACH_OK; }
+    if (std::strcmp(key, "host_threads") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_host_threads = value; return PRACH_OK; }
+    if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
+    return PRACH_ERR_ARG;
+}
+
+int prach_device_glibc_stream(prach_engine *e, uint32_t seed, uint64_t first, uint64_t n, int32_t *out) {
+    if (!e || !out || n == 0) return PRACH_ERR_ARG;
+    PRACH_GUARD(
+        HIPCHK(hipSetDevice(e->device));
+        const size_t nchunks = (n + STREAM_CHUNK - 1) / STREAM_CHUNK;
+        const size_t need = align_up(4 * 31 * nchunks, 256) + 4 * (n + 2);
+        { int rc = ensure_arena(e, need); if (rc != PRACH_OK) return rc; }
+        std::vector<uint32_t> seeds(31 * nchunks);
+        prach_internal_glibc_seeds(seed, first, nchunks, STREAM_CHUNK, seeds.data());
+        HIPCHK(hipMemcpy(e->arena, seeds.data(), 4 * 31 * nchunks, hipMemcpyHostToDevice));
+        int *dout = reinterpret_cast<int *>(e->arena + align_up(4 * 31 * nchunks, 256));
+        HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(e->arena), dout, n, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
+        return PRACH_OK;
+    )
+}
+
+int prach_last_timing(const prach_engine *e, prach_timing *out) {
+    if (!e || !out) return PRACH_ERR_ARG;
+    *out = e->last;
+    return PRACH_OK;
+}
+
+int prach_run_trials(prach_engine *e, const prach_cfg *cfgs, int n, prach_result *results, prach_ue_log *const *ue_logs) {
+    if (!e || !cfgs || !results || n <= 0) return PRACH_ERR_ARG;
+    PRACH_GUARD(return run_trials_impl(e, cfgs, n, results, ue_logs);)
 }
 
 } // extern "C"

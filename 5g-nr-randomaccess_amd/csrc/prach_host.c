@@ -11,6 +11,7 @@
 
 #include <errno.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -66,6 +67,7 @@ const char *prach_strerror(int s) {
     case PRACH_ERR_STREAM: return "glibc draw stream exhausted";
     case PRACH_ERR_INTERNAL: return "device-side consistency check failed";
     case PRACH_ERR_IO: return "I/O error";
+    case PRACH_ERR_TIMEOUT: return "a workgroup of a cluster waited too long for a peer (cluster not co-resident)";
     default: return "unknown status";
     }
 }
@@ -143,10 +145,19 @@ static uint32_t philox31(uint64_t seed, uint32_t nUE, uint32_t variant, uint32_t
 
 int prach_noma_activation_table(const prach_cfg *c, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
                                 uint32_t *ndraws) {
-    if (!c || !preamble0 || !sector || !gain || !lgain || !ndraws) return PRACH_ERR_ARG;
+    if (!c) return PRACH_ERR_ARG;
+    return prach_noma_activation_range(c, 0, c->nUE, preamble0, sector, gain, lgain, ndraws);
+}
+
+/* UEs [lo, hi) of the table (outputs indexed from lo): every UE's draws are its own Philox counter, so ranges are
+ * independent and the engine deals them to all host cores. */
+int prach_noma_activation_range(const prach_cfg *c, int lo, int hi, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
+                                uint32_t *ndraws) {
+    if (!c || !preamble0 || !sector || !gain || !lgain || !ndraws || lo < 0 || hi > c->nUE || lo > hi) return PRACH_ERR_ARG;
+    preamble0 -= lo; sector -= lo; gain -= lo; lgain -= lo; ndraws -= lo;
     const float pi = 3.14; /* NOMA.c:55 */
     const float cellRadius = c->cellRadius;
-    for (int i = 0; i < c->nUE; i++) {
+    for (int i = lo; i < hi; i++) {
         uint32_t k = 0;
 #define DRAW() ((int)philox31(c->seed, (uint32_t)c->nUE, PRACH_VARIANT_NOMA_C, (uint32_t)i, k++))
         preamble0[i] = DRAW() % c->nPreamble; /* NOMA.c:133 */
@@ -196,7 +207,7 @@ size_t prach_format_noma_line(const prach_cfg *c, const prach_result *r, char *b
  * chunk c of `chunk` outputs starting at output `first`, the window that precedes its first value. */
 typedef struct { uint32_t m[31][31]; } lfg_mat;
 static lfg_mat lfg_pow2[48];
-static int lfg_pow2_ready = 0;
+static pthread_once_t lfg_pow2_once = PTHREAD_ONCE_INIT; /* engines of several host threads may need it at once */
 
 static void lfg_matmul(const lfg_mat *a, const lfg_mat *b, lfg_mat *out) {
     for (int i = 0; i < 31; i++)
@@ -213,14 +224,13 @@ static void lfg_matvec(const lfg_mat *a, const uint32_t *w, uint32_t *out) {
         out[i] = acc;
     }
 }
-static void lfg_init_pows(void) {
-    if (lfg_pow2_ready) return;
+static void lfg_build_pows(void) {
     memset(&lfg_pow2[0], 0, sizeof(lfg_mat));
     for (int j = 0; j < 30; j++) lfg_pow2[0].m[j][j + 1] = 1; /* w'[j] = w[j+1] */
     lfg_pow2[0].m[30][0] = 1; lfg_pow2[0].m[30][28] = 1;      /* w'[30] = r[n+1] = r[n-30] + r[n-2] = w[0] + w[28] */
     for (int j = 1; j < 48; j++) lfg_matmul(&lfg_pow2[j - 1], &lfg_pow2[j - 1], &lfg_pow2[j]);
-    lfg_pow2_ready = 1;
 }
+static void lfg_init_pows(void) { pthread_once(&lfg_pow2_once, lfg_build_pows); }
 static void lfg_jump(uint32_t *w, uint64_t d) {
     uint32_t t[31];
     for (int j = 0; d; j++, d >>= 1)

@@ -79,7 +79,7 @@ __device__ __forceinline__ long long nwait(const PRACH_G long long *p, unsigned 
     unsigned spins = 0;
     while (!nok(g, tag)) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > NSPIN_LIMIT) { *status_word = PRACH_ERR_INTERNAL; break; }
+        if (++spins > NSPIN_LIMIT) { *status_word = PRACH_ERR_TIMEOUT; break; } // peer not resident? the engine reruns with one workgroup per trial
         g = nld(p);
     }
     return g;
@@ -91,7 +91,8 @@ size_t noma_kernel_lds_bytes(int nP) { return sizeof(double) * 2 * 6 * 64 + size
 
 __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = blockIdx.x % nT, b = blockIdx.x / nT;
+    const int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
+    (void)nT;
     const TrialG P(params[T]);
     const NLds L = ncarve(smem, P.nP);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -454,6 +455,14 @@ hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int ma
     if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(noma_kernel, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
     return hipGetLastError();
+}
+
+int noma_kernel_blocks_per_cu(int maxP) {
+    const size_t lds = noma_kernel_lds_bytes(maxP);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&noma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&noma_kernel), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;
+    return nb;
 }
 
 } // namespace prach

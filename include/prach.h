@@ -43,6 +43,9 @@ extern "C" {
 #define PRACH_ERR_STREAM        -4 /* glibc draw stream exhausted (engine retries internally) */
 #define PRACH_ERR_INTERNAL      -5 /* device-side consistency check failed */
 #define PRACH_ERR_IO            -6
+#define PRACH_ERR_TIMEOUT       -7 /* a workgroup of a trial's cluster waited too long for a peer workgroup (the cluster was not
+                                      wholly resident, e.g. another process holds CUs): the engine reruns such a trial on a
+                                      kernel that waits for nobody and counts it in prach_timing; callers never see it */
 
 typedef struct prach_cfg {
     int32_t variant;        /* PRACH_VARIANT_* */
@@ -91,11 +94,17 @@ typedef struct prach_ue_log {
 
 typedef struct prach_timing {
     double kernel_ms;     /* HIP-event time of the simulation kernel launch(es) of the last call, on the engine's stream */
-    double upload_ms;     /* host->device staging (schedules, parameters, glibc stream seeds) */
+    double upload_ms;     /* host->device staging (schedules, parameters, glibc stream seeds; NOMA_C: the activation tables) */
     double total_ms;      /* wall time of the whole call */
     int32_t launches;     /* kernel launches in the last call */
-    int32_t workgroups;   /* workgroups per launch */
+    int32_t workgroups;   /* workgroups of the last launch */
     uint64_t updates;     /* sum over trials of nUE * steps */
+    int32_t cluster_size;    /* workgroups per trial of the last launch (0: the one-workgroup fallback kernel) */
+    int32_t resident_limit;  /* workgroups the runtime's occupancy query admits at once for the cluster kernel and its LDS
+                                size; a cluster launch never exceeds it (its workgroups wait for each other) */
+    int32_t fallback_trials; /* trials of the last call that a cluster launch could not finish and that were rerun (exactly) on
+                                a kernel that waits for nobody: a per-subframe capacity exceeded, or a peer wait timed out */
+    int32_t spin_timeouts;   /* ... of which: peer waits that timed out (PRACH_ERR_TIMEOUT) */
 } prach_timing;
 
 typedef struct prach_engine prach_engine;
@@ -117,7 +126,9 @@ int prach_last_timing(const prach_engine *, prach_timing *out);
  *   "legacy"        1: run on the one-workgroup-per-trial kernel (the exact fallback of every capacity check)
  *   "dense"         1: cluster kernel without the compacted two-phase pass
  *   "wide_records"  1: 16-byte hot records also with one workgroup per trial
- *   "pipeline"      0: a cluster does not run phase A of the next subframe during the exchange of the current one */
+ *   "pipeline"      0: a cluster does not run phase A of the next subframe during the exchange of the current one
+ *   "resident"      test hook: treat only this many workgroups as co-resident (0 = ask the runtime's occupancy query)
+ *   "host_threads"  NOMA_C: host threads that build the activation tables (0 = all cores) */
 int prach_engine_set(prach_engine *, const char *key, int64_t value);
 
 /* Host-side pieces of the same seam (no device needed) */
@@ -140,6 +151,9 @@ const char *prach_strerror(int status);
  * so the device-side sort / pairing is bit-identical to the reference; the per-subframe loop is on the GPU.
  * Philox mode only (draw k of UE i; the rejection loops make the glibc stream position data dependent). */
 int prach_noma_activation_table(const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
+                                uint32_t *ndraws);
+/* the same for the UEs [lo, hi) only (outputs indexed from lo): ranges are independent, the engine builds them on all host cores */
+int prach_noma_activation_range(const prach_cfg *cfg, int lo, int hi, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
                                 uint32_t *ndraws);
 size_t prach_format_noma_line(const prach_cfg *, const prach_result *, char *buf, size_t cap); /* NOMA.c:606-632 */
 

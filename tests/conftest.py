@@ -23,11 +23,23 @@ def ob():
     return binding
 
 
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t + 1.0 for s in sources)
+
+
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package (ctypes binding of libprach_hip.so). Built on demand."""
+    """The product package (ctypes binding of libprach_hip.so).  Built on demand: when the library or the CLI binary is
+    missing or older than a source file (neither is tracked in git)."""
+    import glob
     import __graft_entry__ as g
-    if not os.path.exists(os.path.join(g.PKG_DIR, "libprach_hip.so")):
+    csrc = os.path.join(g.PKG_DIR, "csrc")
+    srcs = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.c")) + \
+        [os.path.join(ROOT, "include", "prach.h")]
+    if any(_stale(os.path.join(g.PKG_DIR, f), srcs) for f in ("libprach_hip.so", "libprach_hip_tinyq.so", "prach_sim")):
         g.build()
     return g.load_package()
 

@@ -132,6 +132,51 @@ def test_many_concurrent_trials_sweep_times(pkg, ob, engine):
                (o.nSuccessUE, o.time_exit, o.collisionPreambles, o.totalPreambleTxop, o.sumTimer, o.draws)
 
 
+def test_config3_full_size_streaming_regime(pkg, ob, engine):
+    """BASELINE config 3 AS THE BENCH LAUNCHES IT: nUE sweep 10k..100k x --times 100 = 1000 RandomAccessWithNOMA Philox trials
+    in ONE call — one workgroup per trial, 8 + 4 byte hot records (the streaming regime; RandomAccessWithNOMA.c:216-221 runs
+    the same grid serially).  Every counter of the 20 trials seed in {0, 1} x all ten nUE points against the oracle, every
+    logged field of every UE of the two 100 000-UE ones; the other 980 trials through size-independent properties of the
+    procedure; the whole call twice (determinism)."""
+    points = list(range(10000, 100001, 10000))
+    cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_WITHNOMA_C, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(100) for n in points]
+    want = [k for k, c in enumerate(cfgs) if c.nUE == 100000 and int(c.seed) in (0, 1)]
+    res, logs = engine.run_trials(cfgs, want_logs=want)
+    tm = engine.timing()
+    assert tm.launches == 1 and tm.workgroups == 1000 and tm.fallback_trials == 0  # G = 1: one workgroup per trial, no rerun
+    import concurrent.futures as cf
+
+    def oracle(k):
+        c = cfgs[k]
+        return k, ob.run_trial(ob.make_cfg(c.nUE, variant=1), ob.Rng(ob.RNG_PHILOX, int(c.seed)), want_ues=k in want)
+
+    checked = [k for k, c in enumerate(cfgs) if int(c.seed) in (0, 1)]
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:  # (the oracle is plain C behind ctypes: no GIL)
+        for k, (ores, oues) in ex.map(oracle, checked):
+            r = res[k]
+            assert r.status == 0
+            bad = {f: (getattr(r, f), getattr(ores, f)) for f in KEYS if getattr(r, f) != getattr(ores, f)}
+            assert not bad and r.totalDelay == ores.totalDelay, (cfgs[k].nUE, int(cfgs[k].seed), bad)
+            if k in want:
+                assert_same(pkg, r, logs[k], ores, oues, ("config3", cfgs[k].nUE, int(cfgs[k].seed)))
+    seen = {}
+    for c, r in zip(cfgs, res):
+        n = c.nUE
+        assert r.status == 0
+        assert r.nSuccessUE + r.failedUEs == n and r.finalSuccessUEs == r.nSuccessUE and r.activeCheck == n
+        assert (r.steps == 10000 and r.time_exit == 10000) or (r.nSuccessUE == n and r.steps == r.time_exit + 1)
+        assert 0 < r.nSuccessUE <= n and r.preambleTxCount >= r.nSuccessUE      # every success transmitted at least once
+        assert 17 * r.nSuccessUE <= r.sumTimer <= 10000 * r.nSuccessUE           # 1 + 11 + 6 subframes at the very least (Beta.c:340,378)
+        assert r.collisionPreambles <= r.totalPreambleTxop and r.failCounts <= r.continueFaliedUEs
+        assert r.draws >= 3 * n                                                  # two activation draws + a preamble per UE (WithNOMA:393-394)
+        if n >= 50000:
+            assert abs(r.nSuccessUE - 18800) < 700                               # 12 grants per 5 ms: the cell saturates (results.csv:5-10)
+        seen.setdefault(n, set()).add((r.nSuccessUE, r.sumTimer, r.totalPreambleTxop))
+    assert all(len(v) > 90 for v in seen.values())                               # the seeds really are different trials
+    res2, _ = engine.run_trials(cfgs)
+    assert [r.as_dict() for r in res2] == [r.as_dict() for r in res]
+
+
 def test_max_steps_and_stream_offset(pkg, ob, engine):
     cfg = pkg.make_cfg(8000, variant=1, rng_mode=0, seed=9, max_steps=2500)
     (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
@@ -228,6 +273,62 @@ def test_cluster_capacity_fallback_is_exact(pkg, ob, engine):
     assert engine.timing().launches == 2  # cluster attempt + exact rerun
     ores, oues = ob.run_trial(ob.make_cfg(60000, variant=1, **kw), ob.Rng(ob.RNG_PHILOX, 2))
     assert_same(pkg, res, logs, ores, oues, "fallback")
+
+
+def test_cluster_residency_is_explicit(pkg, ob, engine):
+    """The workgroups of a cluster wait for each other, so a cluster launch is capped by what the runtime's occupancy query
+    admits at once for the kernel and its LDS size (prach_timing.resident_limit); the "resident" hook narrows it."""
+    cfgs = [pkg.make_cfg(20000, variant=1, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(3)]
+    engine.set("cluster", 16)
+    try:
+        res, _ = engine.run_trials(cfgs)
+        tm = engine.timing()
+        assert tm.resident_limit >= 256 and tm.cluster_size == 16 and tm.workgroups == 48 and tm.fallback_trials == 0
+        engine.set("resident", 30)  # 3 trials x 16 workgroups do not fit: 8 per trial do
+        res2, _ = engine.run_trials(cfgs)
+        tm = engine.timing()
+        assert tm.resident_limit == 30 and tm.cluster_size == 8 and tm.workgroups == 24 and tm.fallback_trials == 0
+        assert [r.as_dict() for r in res2] == [r.as_dict() for r in res]
+    finally:
+        engine.set("resident", 0)
+        engine.set("cluster", 0)
+
+
+def test_two_engines_share_one_device(pkg, ob):
+    """Two engines (two host threads, two HIP streams) on ONE device, each launching 4 trials x 64 workgroups at the same
+    time: together more workgroups than the device holds.  Members of a cluster are consecutive blocks, so whole clusters
+    are resident in dispatch order; a cluster whose peers are late is bounded by the peer-wait limit and rerun exactly on
+    the one-workgroup kernel — never silently: prach_timing reports how many."""
+    import threading
+    cfgs = [pkg.make_cfg(30000 + 2000 * k, variant=k & 1, rng_mode=pkg.RNG_PHILOX, seed=40 + k) for k in range(4)]
+    out = {}
+
+    def run(tag):
+        eng = pkg.Engine(0)
+        try:
+            eng.set("cluster", 64)
+            for rep in range(2):
+                res, _ = eng.run_trials(cfgs)
+                tm = eng.timing()
+                out[(tag, rep)] = ([r.as_dict() for r in res], tm.fallback_trials, tm.spin_timeouts, tm.cluster_size)
+        finally:
+            eng.close()
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert len(out) == 4
+    exp = []
+    for c in cfgs:
+        o, _ = ob.run_trial(ob.make_cfg(c.nUE, variant=c.variant), ob.Rng(ob.RNG_PHILOX, int(c.seed)), want_ues=False)
+        exp.append(o)
+    for (tag, rep), (res, nfb, nto, G) in out.items():
+        assert 0 <= nto <= nfb <= 4, (tag, rep, nfb, nto)
+        for r, o in zip(res, exp):
+            assert r["status"] == 0
+            assert {k: r[k] for k in KEYS} == {k: getattr(o, k) for k in KEYS}, (tag, rep)
 
 
 def test_legacy_kernel_option(pkg, ob, engine):

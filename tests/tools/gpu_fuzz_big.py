@@ -1,5 +1,5 @@
 import sys, time, os
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import __graft_entry__ as g
