@@ -75,7 +75,12 @@ struct CLds {
     int *gsum;    // [GSCAP] glibc mode: rand() calls of every 64-UE group in this subframe's UE loop
     int *gpre;    // [GSCAP] their exclusive prefix in index order
     unsigned *gmask; // [4 * GSCAP / 2] compacted glibc pass: per OWN group, lanes that draw once or twice (2 words) / twice (2 words)
+    // LDS-resident clusters (REC_L16): the hot record and the Philox draw index of every owned UE (slot = local group * 64 + lane)
+    int4 *lrec;      // [lslots]
+    unsigned *lnd;   // [lslots]
+    int2 *lcand;     // [LCANDCAP] early-leaver candidates of this subframe (more: global scratch)
 };
+constexpr int LCANDCAP = 1024;
 constexpr int GBINS = 1024;
 #ifndef PRACH_QCAP
 #define PRACH_QCAP 8192
@@ -120,7 +125,7 @@ __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b
     }
 }
 
-__device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc) {
+__device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc, int lslots) {
     CLds L;
     L.gev = reinterpret_cast<int2 *>(smem);
     int *ip = reinterpret_cast<int *>(smem + sizeof(int2) * EVCAPC);
@@ -133,9 +138,16 @@ __device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc) {
     L.wtot = ip; ip += NW;
     L.hist = ip; ip += 2 * nP; L.mloc = ip; ip += 2 * nP; L.mloc_stay = ip; ip += 2 * nP; L.cand_n = ip; ip += 2 * nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
     L.lcall = ip; ip += 2 * nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
-    L.queue = ip; ip += QCAP;
+    L.queue = ip; ip += lslots > 0 ? lslots : QCAP; // (LDS-resident: every owned UE fits the queue)
     L.gsum = ip; L.gpre = ip + GSCAP; L.gmask = reinterpret_cast<unsigned *>(ip + 2 * GSCAP); // only carved (and only touched) in glibc mode
     (void)glibc;
+    L.lrec = nullptr; L.lnd = nullptr; L.lcand = nullptr;
+    if (lslots > 0) { // (never together with glibc mode)
+        ip += (4 - ((ip - reinterpret_cast<int *>(smem)) & 3)) & 3; // 16-byte alignment of the records
+        L.lrec = reinterpret_cast<int4 *>(ip); ip += 4 * lslots;
+        L.lnd = reinterpret_cast<unsigned *>(ip); ip += lslots;
+        L.lcand = reinterpret_cast<int2 *>(ip); ip += 2 * LCANDCAP;
+    }
     return L;
 }
 
@@ -170,10 +182,23 @@ __device__ __forceinline__ long long wait_granule(const PRACH_G long long *p, un
     return g;
 }
 
-template <bool H8_>
+// Where the hot records of a trial live:
+//   REC_G16  global memory, 16 bytes per UE (clusters whose owned UEs do not fit LDS; the glibc modes; the dense pass)
+//   REC_H8   global memory, 8 + 4 bytes per UE (one workgroup per trial: the streaming regime)
+//   REC_L16  LDS: a cluster workgroup keeps the 16-byte record AND the Philox draw index of every UE it owns resident for the
+//            whole trial (49 groups x 64 UEs x 20 bytes = 63 KB at nUE = 100 000, G = 32): the pass, the event body and the grant
+//            never touch L2 for a record; global memory only sees the cold per-UE fields and the final state
+constexpr int REC_G16 = 0, REC_H8 = 1, REC_L16 = 2;
+template <int REC_>
 struct CtxT {
-    static constexpr bool H8 = H8_; // 8 + 4 byte hot record (one workgroup per trial, streaming) or the engine's 16-byte record
+    static constexpr int REC = REC_;
+    static constexpr bool H8 = REC_ == REC_H8;   // 8 + 4 byte hot record (one workgroup per trial, streaming)
+    static constexpr bool LREC = REC_ == REC_L16; // LDS-resident records
     int b, G, evw, mbstride;
+    FastMod fmG;         // LREC: slot of an owned UE = ((idx >> 6) - b) / G * 64 + (idx & 63)
+    int4 *lrec;          // LREC: [lslots]
+    unsigned *lnd;       // LREC: [lslots] Philox draw index
+    int2 *lcand;         // LREC: [LCANDCAP]
     PRACH_G int *mbox;   // [2][G][mbstride ints]: per workgroup 1 header + nP bucket + evw event granules
     PRACH_G v2i_t *cand; // this workgroup's private early-leaver candidate scratch
     PRACH_G v4i_t *rec;  // [nUE] the 16-byte record (H8 == false)
@@ -203,14 +228,29 @@ __device__ __forceinline__ v2i_t hot_encode(const int tx, const int bo, const in
     return h;
 }
 __device__ __forceinline__ bool hot_fits(const int tx, const int bo) { return (unsigned)(tx + 1) <= 0xffffu && (unsigned)(bo + HOT_BO_BIAS) <= 0xffffu; }
+// LREC: the LDS slot of UE i (owned by this workgroup: (i >> 6) - b is a multiple of G) and back
 template <class CX>
-__device__ __forceinline__ int4 hot_load_full(const CX &C, const int i) { // non-temporal: the grant bit is set by an L2 atomic
+__device__ __forceinline__ int slot_of(const CX &C, const int i) {
+    const unsigned x = (unsigned)((i >> 6) - C.b);
+    unsigned q = C.fmG.d == 1u ? x : __umulhi(x, C.fmG.M);
+    q += (x - q * C.fmG.d) != 0u ? 1u : 0u; // the quotient estimate is at most 1 short; x is an exact multiple
+    return (int)(q * 64u) + (i & 63);
+}
+template <class CX>
+__device__ __forceinline__ int idx_of(const CX &C, const int slot) { return (C.b + C.G * (slot >> 6)) * 64 + (slot & 63); }
+
+// (slot: only read when CX::LREC)
+template <class CX>
+__device__ __forceinline__ int4 hot_load_full(const CX &C, const int i, const int slot) { // non-temporal: the grant bit is set by an L2 atomic
+    if (CX::LREC) return C.lrec[slot];
     if (CX::H8) return hot_decode(__builtin_nontemporal_load(C.hot + (unsigned)i), C.tbase[(unsigned)i]);
     return load_rec(C.rec + (unsigned)i);
 }
 template <class CX>
-__device__ __forceinline__ void hot_store_full(const CX &C, const int i, const int4 r) {
-    if (CX::H8) {
+__device__ __forceinline__ void hot_store_full(const CX &C, const int i, const int slot, const int4 r) {
+    if (CX::LREC) {
+        C.lrec[slot] = r;
+    } else if (CX::H8) {
         if (!hot_fits(r.x, r.z)) *C.status_word = PRACH_ERR_INTERNAL;
         C.hot[(unsigned)i] = hot_encode(r.x, r.z, r.w);
         C.tbase[(unsigned)i] = r.y;
@@ -219,20 +259,29 @@ __device__ __forceinline__ void hot_store_full(const CX &C, const int i, const i
     }
 }
 template <class CX>
-__device__ __forceinline__ void hot_grant(const CX &C, const int i) {
-    if (CX::H8) __hip_atomic_fetch_or(reinterpret_cast<PRACH_G unsigned *>(C.hot + (unsigned)i), PK_GRANT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void hot_grant(const CX &C, const int i, const int slot) {
+    if (CX::LREC) atomicOr(reinterpret_cast<unsigned *>(&C.lrec[slot].w), PK_GRANT_BIT);
+    else if (CX::H8) __hip_atomic_fetch_or(reinterpret_cast<PRACH_G unsigned *>(C.hot + (unsigned)i), PK_GRANT_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else grant_rec(C.rec + (unsigned)i);
 }
 // what phase A reads and writes: everything but the timer base
 template <class CX>
-__device__ __forceinline__ int4 hot_load_pass(const CX &C, const unsigned i) {
+__device__ __forceinline__ int4 hot_load_pass(const CX &C, const unsigned i, const int slot) {
+    if (CX::LREC) return C.lrec[slot];
     if (CX::H8) return hot_decode(__builtin_nontemporal_load(C.hot + i), 0);
     return load_rec(C.rec + i);
 }
 template <class CX>
-__device__ __forceinline__ void hot_store_pass(const CX &C, const unsigned i, const int4 r) {
-    if (CX::H8) C.hot[i] = hot_encode(r.x, r.z, r.w);
+__device__ __forceinline__ void hot_store_pass(const CX &C, const unsigned i, const int slot, const int4 r) {
+    if (CX::LREC) C.lrec[slot] = r;
+    else if (CX::H8) C.hot[i] = hot_encode(r.x, r.z, r.w);
     else store_rec(C.rec + i, r);
+}
+template <class CX>
+__device__ __forceinline__ unsigned nd_load(const TrialG &P, const CX &C, const int i, const int slot) { return CX::LREC ? C.lnd[slot] : P.nd[i]; }
+template <class CX>
+__device__ __forceinline__ void nd_store(const TrialG &P, const CX &C, const int i, const int slot, const unsigned v) {
+    if (CX::LREC) C.lnd[slot] = v; else P.nd[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,7 +295,7 @@ __device__ __forceinline__ void hot_store_pass(const CX &C, const unsigned i, co
 template <int MODE, class CX>
 __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX &C, const FastMods &FM, const int *fcall, const int *lcall,
                                         const int t, const int prevAC, PRACH_G long long *mbev, const unsigned tag, const unsigned long long stepbase,
-                                        const int lane, const int g, const int jdead, const int i, const bool valid, const int4 r, unsigned ndc,
+                                        const int lane, const int g, const int jdead, const int i, const int slot, const bool valid, const int4 r, unsigned ndc,
                                         int &c_succ, int &c_contf) {
     constexpr bool FINAL = MODE == 3, COUNT = MODE == 1 || MODE == 4, SELECT = MODE == 2 || MODE == 5;
     const int aT = P.aT, nUE = P.nUE;
@@ -283,7 +332,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         dirty = true;
     }
     if (FINAL) {
-        if (dirty) hot_store_full(C, i, pack(u));
+        if (dirty) hot_store_full(C, i, slot, pack(u));
         return;
     }
     // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
@@ -316,7 +365,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
             atomicOr(&L.gmask[4 * jl + (ln >> 5)], 1u << (ln & 31));
             if (need == 2) atomicOr(&L.gmask[4 * jl + 2 + (ln >> 5)], 1u << (ln & 31));
         }
-        if (dirty) hot_store_full(C, i, pack(u));
+        if (dirty) hot_store_full(C, i, slot, pack(u));
         return;
     }
 
@@ -440,11 +489,16 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_NCAND], __popcll(cm));
             base = __shfl(base, 0);
-            if (eclass) { store_i2(&C.cand[base + __popcll(cm & lanemask_lt(lane))], i, oldp); atomicAdd(&L.cand_n[oldp], 1); }
+            if (eclass) {
+                const int cs = base + __popcll(cm & lanemask_lt(lane));
+                if (CX::LREC && cs < LCANDCAP) C.lcand[cs] = make_int2(i, oldp);
+                else store_i2(&C.cand[cs], i, oldp);
+                atomicAdd(&L.cand_n[oldp], 1);
+            }
         }
     }
-    if (nd_dirty) P.nd[i] = ndc;
-    if (dirty) hot_store_full(C, i, pack(u));
+    if (nd_dirty) nd_store(P, C, i, slot, ndc);
+    if (dirty) hot_store_full(C, i, slot, pack(u));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,8 +522,9 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
     auto fetch = [&](int jj, int4 &rr, unsigned &nn, bool &ok) {
         const int in = (C.b + C.G * max(jj, 0)) * 64 + lane;
         ok = jj >= 0 && in < activeCheck;
-        rr = hot_load_full(C, ok ? in : 0);
-        nn = MODE == 0 ? P.nd[ok ? in : 0] : 0u;
+        const int sl = max(jj, 0) * 64 + lane;
+        rr = hot_load_full(C, ok ? in : 0, sl);
+        nn = MODE == 0 ? nd_load(P, C, ok ? in : 0, sl) : 0u;
     };
     int jA = next_live(w), jB;
     int4 rA, rB;
@@ -487,7 +542,7 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
         jA = jB; rA = rB; ndA = ndB; okA = okB;
         jB = jA >= 0 ? next_live(jA + NW) : -1;
         fetch(jB, rB, ndB, okB);
-        ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, g, j, i, i < activeCheck, r, ndc, c_succ, c_contf);
+        ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, g, j, i, j * 64 + lane, i < activeCheck, r, ndc, c_succ, c_contf);
     }
     if (!FINAL) {
 #pragma unroll
@@ -535,7 +590,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     // ignore it): nothing has to be merged with a default value, so nothing is waited for before the record is used.
     const unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
     auto fetch = [&](int jj) -> int4 { // H8: 8 bytes per UE, the timer base (.y) is not needed here
-        return hot_load_pass(C, min((unsigned)((C.b + C.G * jj) * 64 + lane), lastrec));
+        return hot_load_pass(C, min((unsigned)((C.b + C.G * jj) * 64 + lane), lastrec), max(jj, 0) * 64 + lane);
     };
     const unsigned rarlim = (unsigned)(maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
     // ---- phase A ----
@@ -575,7 +630,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
             // from the record's age, so the record is NOT rewritten (ue_step brings it up to date when something happens)
             if (pg != (unsigned)PEND_STAY) {
                 const unsigned npk = ((pk & 0x0FFFFFFFu) + (1u << PK_RAR_SHIFT)) | (member ? (unsigned)PEND_STAY << PK_PEND_SHIFT : 0u);
-                hot_store_pass(C, (unsigned)i, make_int4(bump ? t : r.x, r.y, r.z, (int)npk));
+                hot_store_pass(C, (unsigned)i, j * 64 + lane, make_int4(bump ? t : r.x, r.y, r.z, (int)npk));
             }
             if (member) {
                 const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
@@ -590,8 +645,8 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_QN], n);
             base = __shfl(base, 0);
-            if (base + n <= QCAP) {
-                if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = i;
+            if (CX::LREC || base + n <= QCAP) { // (LDS-resident: the queue holds slots and has room for every owned UE)
+                if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = CX::LREC ? j * 64 + lane : i;
             } else if (SPEC) { // cannot happen: the kernel runs ahead only if every owned UE fits the queue
                 if (lane == 0) L.scal[C_STATUS] = PRACH_ERR_INTERNAL;
             } else { // queue full: this wavefront does its events in place
@@ -599,7 +654,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
                 unsigned ndc = 0;
                 int4 rf = make_int4(-1, 0, 0, 0);
                 if (heavy) { ndc = P.nd[i]; rf = CX::H8 ? make_int4(r.x, C.tbase[(unsigned)i], r.z, r.w) : r; }
-                ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, g, -1, i, heavy, rf, ndc, c_succ, c_contf);
+                ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, g, -1, i, 0, heavy, rf, ndc, c_succ, c_contf);
             }
         }
     };
@@ -642,14 +697,15 @@ __device__ __forceinline__ void compact_phase_b(const TrialG &P, const CLds &L, 
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int c_succ = 0, c_contf = 0;
     // ---- phase B ----
-    const int qn = min(L.scal[C_QN], L.scal[C_QEND]);
+    const int qn = CX::LREC ? L.scal[C_QN] : min(L.scal[C_QN], L.scal[C_QEND]);
     for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
         const bool v = q0 + lane < qn;
-        const int i = v ? L.queue[q0 + lane] : 0;
+        const int qe = v ? L.queue[q0 + lane] : 0;
+        const int slot = CX::LREC ? qe : 0, i = CX::LREC ? idx_of(C, qe) : qe;
         int4 r = make_int4(-1, 0, 0, 0);
         unsigned ndc = 0;
-        if (v) { r = hot_load_full(C, i); if (MODE == 0) ndc = P.nd[i]; }
-        ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, i >> 6, -1, i, v, r, ndc, c_succ, c_contf);
+        if (v) { r = hot_load_full(C, i, slot); if (MODE == 0) ndc = nd_load(P, C, i, slot); }
+        ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, i >> 6, -1, i, slot, v, r, ndc, c_succ, c_contf);
     }
     if (__any((c_succ | c_contf) != 0)) { // (most wavefronts, most subframes: nothing to add)
 #pragma unroll
@@ -735,23 +791,23 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fca
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
-template <bool GLIBC, bool H8>
-__global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
+template <bool GLIBC, int REC>
+__global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the workgroups of a cluster are CONSECUTIVE blocks: in-order dispatch completes whole clusters even when not every
     // block of the grid is resident at once (the engine keeps G x trials within the occupancy query's answer anyway)
     const int T = blockIdx.x / G, b = blockIdx.x % G;
-    (void)nT;
     const TrialG P(params[T]);
-    const CLds L = ccarve(smem, P.nP, GLIBC);
+    const CLds L = ccarve(smem, P.nP, GLIBC, REC == REC_L16 ? lslots : 0);
     const int tid = threadIdx.x;
     const int nUE = P.nUE, nP = P.nP, aT = P.aT;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
 
     FastMods FM;
     FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
-    CtxT<H8> C;
+    CtxT<REC> C;
     C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox;
+    C.fmG = make_fastmod(G); C.lrec = L.lrec; C.lnd = L.lnd; C.lcand = L.lcand;
     C.status_word = &L.scal[C_STATUS];
     C.rec = P.rec;
     C.hot = reinterpret_cast<PRACH_G v2i_t *>(P.rec);
@@ -763,9 +819,10 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     // calloc + initialUE (Beta.c:78-83) for the groups this workgroup owns
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
+        if (REC == REC_L16) { L.lrec[x] = make_int4(-1, 0, 0, 0); L.lnd[x] = 0u; } // (every slot, also past the last UE)
         if (g < totgroups && i < nUE) {
-            hot_store_full(C, i, make_int4(-1, 0, 0, 0));
-            P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0; P.nd[i] = 0;
+            if (REC != REC_L16) { hot_store_full(C, i, 0, make_int4(-1, 0, 0, 0)); P.nd[i] = 0; }
+            P.ptc[i] = 0; P.ftt[i] = 0; P.stt[i] = 0; P.fcnt[i] = 0;
         }
     }
     for (int k = tid; k < nP; k += WG_THREADS) {
@@ -781,7 +838,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = P.stop;
     unsigned long long steps = 0;
-    int status = (lgroups > DEADW * 32 || (GLIBC && totgroups > GSCAP)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (lgroups > DEADW * 32 || (GLIBC && totgroups > GSCAP) || (REC == REC_L16 && lgroups * 64 > lslots)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
     unsigned long long base = 0; // glibc: rand() calls consumed so far (relative to the stream window)
 #ifdef PRACH_STAMPS
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -791,7 +848,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     // Software pipeline of a cluster (G > 1, Philox): phase A of subframe t+1 runs on half of the wavefronts while the other
     // half gathers the exchange of subframe t — it needs nothing of that exchange's outcome except the grants, and the UEs a
     // grant could go to are left for phase B (compact_phase_a<true>).  Needs every owned UE to fit the event queue.
-    const bool pipelined = !GLIBC && !P.dense_pass && P.pipeline && G > 1 && lgroups * 64 <= QCAP;
+    const bool pipelined = !GLIBC && !P.dense_pass && P.pipeline && G > 1 && (REC == REC_L16 || lgroups * 64 <= QCAP);
     int ahead_for = -1; // subframe whose phase A has already run
     auto parity_view = [&](const int par) { CLds V = L; V.hist = L.hist + par * nP; V.mloc = L.mloc + par * nP; V.mloc_stay = L.mloc_stay + par * nP; V.cand_n = L.cand_n + par * nP; return V; };
 
@@ -817,15 +874,16 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         // it.  A granted UE was the only caller of a bucket nobody else stayed matched in, so it is the only one that phase A
         // counted there as matched before (mloc_stay).  (Every owned UE fits the queue when the kernel runs ahead.)
         auto grant = [&](const int my) {
-            hot_grant(C, my);
+            const int myslot = REC == REC_L16 ? slot_of(C, my) : 0;
+            hot_grant(C, my, myslot);
             if (ahead_for == t + 1) {
-                const int4 r = hot_load_pass(C, (unsigned)my);
+                const int4 r = hot_load_pass(C, (unsigned)my, myslot);
                 const unsigned pk = (unsigned)r.w & ~PK_GRANT_BIT;
                 if ((pk >> PK_PEND_SHIFT) == (unsigned)PEND_STAY && light_case(pk, r.x, r.z, t + 1, rarlim_k)) {
                     const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
                     atomicSub(&Ln.hist[p1], 1);
                     Ln.mloc_stay[p1] = INT_MAX;
-                    L.queue[atomicAdd(&L.scal[C_QN], 1)] = my; // ... and its grant is applied by phase B of subframe t+1
+                    L.queue[atomicAdd(&L.scal[C_QN], 1)] = REC == REC_L16 ? myslot : my; // ... and its grant is applied by phase B of subframe t+1
                 }
             }
         };
@@ -909,7 +967,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         // early leavers below this workgroup's lowest caller are the only ones a rank can need
         const int ncand = L.scal[C_NCAND];
         for (int k = tid; k < ncand; k += WG_THREADS) {
-            const v2i_t c = C.cand[k];
+            v2i_t c;
+            if (REC == REC_L16 && k < LCANDCAP) { const int2 cl = L.lcand[k]; c.x = cl.x; c.y = cl.y; }
+            else c = C.cand[k];
             if (c.x < min(Lc.mloc[c.y], Lc.mloc_stay[c.y])) {
                 const int slot = atomicAdd(&L.scal[C_NEV], 1);
                 const int info = EVC_LEAVER | (c.y << 4);
@@ -1163,11 +1223,11 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     for (int x = tid; x < lgroups * 64; x += WG_THREADS) {
         const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
         if (g >= totgroups || i >= nUE) continue;
-        const UeState u = unpack(hot_load_full(C, i));
+        const UeState u = unpack(hot_load_full(C, i, x));
         const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
         const int ptc = P.ptc[i], fc = P.fcnt[i];
         if (u.act == ACT_DONE) { sumT += timer; ptcS += ptc; fcS += fc; }
-        ndS += P.nd[i];
+        ndS += nd_load(P, C, i, x);
         P.timers[i] = u.act == ACT_DONE ? timer : INT_MIN;
         if (P.logs) {
             prach_ue_log o;
@@ -1215,31 +1275,33 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     }
 }
 
-size_t cluster_kernel_lds_bytes(int nP, bool glibc) {
-    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 15 * nP + QCAP + (glibc ? 4 * GSCAP : 0));
+size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots) {
+    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 15 * nP + (lslots > 0 ? lslots : QCAP) + (glibc ? 4 * GSCAP : 0)) +
+           (lslots > 0 ? 16 + (size_t)lslots * 20 + sizeof(int2) * LCANDCAP : 0);
 }
 
 using cluster_kernel_t = void (*)(const TrialDev *, int, int);
-static cluster_kernel_t pick_cluster_kernel(int rng_mode, int compact_records) {
-    const bool glibc = rng_mode == PRACH_RNG_GLIBC;
-    // compact_records: the 8 + 4 byte hot record (streaming regime: one workgroup per trial); else the 16-byte record
-    return glibc ? (compact_records ? cluster_kernel<true, true> : cluster_kernel<true, false>)
-                 : (compact_records ? cluster_kernel<false, true> : cluster_kernel<false, false>);
+// rec_mode: REC_G16 / REC_H8 (one workgroup per trial: the streaming regime) / REC_L16 (clusters, Philox: LDS-resident records)
+static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode) {
+    if (rng_mode == PRACH_RNG_GLIBC) return rec_mode == REC_H8 ? cluster_kernel<true, REC_H8> : cluster_kernel<true, REC_G16>;
+    return rec_mode == REC_L16 ? cluster_kernel<false, REC_L16> : (rec_mode == REC_H8 ? cluster_kernel<false, REC_H8> : cluster_kernel<false, REC_G16>);
 }
 
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream) {
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC);
-    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, compact_records);
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, hipStream_t stream) {
+    if (rec_mode != REC_L16) lslots = 0;
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(fn, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
+    hipLaunchKernelGGL(fn, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, lslots);
     return hipGetLastError();
 }
 
 // workgroups of this kernel (with its dynamic LDS) the runtime admits per CU: what a cooperative launch would be checked against
-int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int compact_records) {
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC);
-    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, compact_records);
+int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots) {
+    if (rec_mode != REC_L16) lslots = 0;
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;

@@ -82,9 +82,13 @@ constexpr int RCCAP = 256;          // reset-cycle re-join candidates per subfra
 
 size_t trial_kernel_lds_bytes(int nP);
 hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream);
-size_t cluster_kernel_lds_bytes(int nP, bool glibc);
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int compact_records, hipStream_t stream);
-int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int compact_records); // occupancy query for the kernel and its dynamic LDS size
+size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots);
+// rec_mode: where / how a trial's hot records are kept (prach_cluster.hip): 0 global 16 B, 1 global 8 + 4 B (one workgroup per
+// trial), 2 LDS-resident (clusters, Philox; lslots = owned UE slots per workgroup, the launch's maximum)
+constexpr int CLUSTER_REC_G16 = 0, CLUSTER_REC_H8 = 1, CLUSTER_REC_L16 = 2;
+constexpr size_t CLUSTER_LDS_LIMIT = 160 * 1024; // LDS per CU (MI355X_MICROARCH.md): one LDS-resident cluster workgroup per CU
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, hipStream_t stream);
+int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots); // occupancy query for the kernel and its dynamic LDS size
 constexpr int STREAM_CHUNK = 31 * 2048; // rand() outputs generated per wavefront (prach_stream.hip)
 hipError_t launch_glibc_stream(const unsigned *seeds, int *out, unsigned long long n, hipStream_t stream);
 extern "C" void prach_internal_glibc_seeds(uint32_t seed, uint64_t first, uint64_t nchunks, uint64_t chunk, uint32_t *out);

@@ -44,7 +44,11 @@ struct prach_engine {
     int64_t opt_pipeline = 1;      // 0: clusters do not run phase A ahead of the exchange (diagnostic)
     int64_t opt_resident = 0;      // test hook: pretend only this many workgroups can be co-resident (0 = ask the runtime)
     int64_t opt_host_threads = 0;  // host threads for the NOMA.c activation tables (0 = all cores)
+#ifdef PRACH_QCAP                  // (the small-queue test build exists to exercise the queue-overflow path of the global-record kernels)
+    int64_t opt_lds_records = 0;
+#else
     int64_t opt_lds_records = 1;   // 0: clusters keep their UE records in global memory (diagnostic)
+#endif
     int num_cus = 256;
 };
 
@@ -204,6 +208,18 @@ static int engine_create_impl(int device, prach_engine **out) {
 }
 
 // one launch over the trials idx[0..m) (all the same rng_mode); attempt = glibc stream retry level
+// LDS-resident records (prach_cluster.hip REC_L16): a Philox cluster whose owned UE slots (the launch's maximum) fit LDS next to
+// the per-subframe structures.  Returns the slot count per workgroup, 0 = records stay in global memory.
+static int lds_record_slots(const prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, int G, int maxP) {
+    if (G <= 1 || !e->opt_lds_records || e->opt_dense || cfgs[idx[0]].rng_mode != PRACH_RNG_PHILOX || cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) return 0;
+    int lslots = 0;
+    for (int k = 0; k < m; k++) {
+        const int groups = (cfgs[idx[k]].nUE + 63) / 64;
+        lslots = std::max(lslots, (groups + G - 1) / G * 64);
+    }
+    return cluster_kernel_lds_bytes(maxP, false, lslots) <= CLUSTER_LDS_LIMIT ? lslots : 0;
+}
+
 static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, prach_result *results,
                      prach_ue_log *const *ue_logs, int attempt, int G, double &kernel_ms, double &upload_ms) {
     const int rng_mode = cfgs[idx[0]].rng_mode;
@@ -327,7 +343,10 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             const prach_cfg &c = cfgs[idx[k]];
             compact = (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 64 < 63000;
         }
-        HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, compact ? 1 : 0, e->stream));
+        const int lslots = lds_record_slots(e, cfgs, idx, m, G, maxP);
+        const int rec_mode = lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16);
+        e->last.rec_mode = rec_mode;
+        HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, e->stream));
     }
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(A), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
@@ -474,7 +493,7 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             int minGroups = INT_MAX;
             for (int k : idx) minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
             int G = (int)e->opt_cluster;
-            const size_t resident = (size_t)resident_workgroups(e, cluster_kernel_blocks_per_cu(maxP, mode, 0));
+            const size_t resident = (size_t)resident_workgroups(e, cluster_kernel_blocks_per_cu(maxP, mode, CLUSTER_REC_G16, 0));
             e->last.resident_limit = (int32_t)resident;
             if (G <= 0) {
                 G = 1;

@@ -105,6 +105,9 @@ typedef struct prach_timing {
     int32_t fallback_trials; /* trials of the last call that a cluster launch could not finish and that were rerun (exactly) on
                                 a kernel that waits for nobody: a per-subframe capacity exceeded, or a peer wait timed out */
     int32_t spin_timeouts;   /* ... of which: peer waits that timed out (PRACH_ERR_TIMEOUT) */
+    int32_t rec_mode;        /* last cluster launch: 0 records in global memory (16 B), 1 global 8 + 4 B (one workgroup per trial),
+                                2 resident in LDS for the whole trial (clusters, Philox) */
+    int32_t reserved;
 } prach_timing;
 
 typedef struct prach_engine prach_engine;
@@ -128,7 +131,8 @@ int prach_last_timing(const prach_engine *, prach_timing *out);
  *   "wide_records"  1: 16-byte hot records also with one workgroup per trial
  *   "pipeline"      0: a cluster does not run phase A of the next subframe during the exchange of the current one
  *   "resident"      test hook: treat only this many workgroups as co-resident (0 = ask the runtime's occupancy query)
- *   "host_threads"  NOMA_C: host threads that build the activation tables (0 = all cores) */
+ *   "host_threads"  NOMA_C: host threads that build the activation tables (0 = all cores)
+ *   "lds_records"   0: clusters keep their UE records in global memory instead of LDS */
 int prach_engine_set(prach_engine *, const char *key, int64_t value);
 
 /* Host-side pieces of the same seam (no device needed) */
