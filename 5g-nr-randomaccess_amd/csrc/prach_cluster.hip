@@ -45,8 +45,13 @@ namespace {
     do {                                                                                               \
         if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); stamps[k] += now_ - tprev; tprev = now_; } \
     } while (0)
+#define FSTAMP(k)                                                                                      \
+    do {                                                                                               \
+        if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); fstamps[k] += now_ - fprev; fprev = now_; } \
+    } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define FSTAMP(k) do { } while (0)
 #endif
 
 constexpr int EVC_CALLER = 1, EVC_RESETCAND = 2, EVC_RJOIN = 3, EVC_LEAVER = 4;
@@ -125,28 +130,61 @@ __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b
     }
 }
 
-__device__ __forceinline__ CLds ccarve(char *smem, int nP, bool glibc, int lslots) {
+// LDS layout: EVERY array sits at a compile-time offset (the per-bucket tables have the fixed stride NPC, whatever nPreamble
+// is), so that an LDS address is an immediate in the ds_* instruction instead of a live scalar register: with run-time
+// offsets the ~25 table pointers alone took a quarter of the wave's SGPR budget and the step loop spilled ~250 SGPRs
+// (v_writelane / v_readlane on the critical path of every phase).  Only the tail of an LDS-resident cluster (records, draw
+// indices: sized by the launch) is addressed through a run-time base.
+constexpr int NPC = 256; // stride of the per-bucket tables (nPreamble <= 254)
+constexpr int LQCAP = CLUSTER_LQCAP; // LDS-resident clusters: event queue = at most every owned UE slot
+namespace lds_off {
+constexpr int GEV = 0;
+constexpr int SIDX = GEV + 8 * EVCAPC;
+constexpr int RCLIST = SIDX + 4 * SCAPC;
+constexpr int SCAL = RCLIST + 4 * RCCAP;
+constexpr int DEAD = SCAL + 4 * 64;
+constexpr int EVOFF = DEAD + 4 * DEADW;
+constexpr int BINS = EVOFF + 4 * (MAXG + 16);
+constexpr int WTOT = BINS + 4 * GBINS;
+constexpr int HIST = WTOT + 4 * NW;       // [2][NPC] by subframe parity, like the next three
+constexpr int MLOC = HIST + 4 * 2 * NPC;
+constexpr int MLOC_STAY = MLOC + 4 * 2 * NPC;
+constexpr int CAND_N = MLOC_STAY + 4 * 2 * NPC;
+constexpr int TOTAL = CAND_N + 4 * 2 * NPC;
+constexpr int FCALL = TOTAL + 4 * NPC;    // [2][NPC]
+constexpr int LCALL = FCALL + 4 * 2 * NPC; // [2][NPC]
+constexpr int NLV = LCALL + 4 * 2 * NPC;
+constexpr int FIE = NLV + 4 * NPC;
+constexpr int QUEUE = FIE + 4 * NPC;
+constexpr int TAIL_G = QUEUE + 4 * QCAP;  // global-record kernels: (glibc) gsum, gpre, gmask follow the QCAP-entry queue
+constexpr int LCAND = QUEUE + 4 * LQCAP;  // LDS-resident kernels: LQCAP-entry queue, candidate list, then the launch-sized tail
+constexpr int TAIL_L = LCAND + 8 * LCANDCAP;
+} // namespace lds_off
+static_assert(lds_off::SIDX % 16 == 0 && lds_off::TAIL_L % 16 == 0, "16-byte alignment of the event and record arrays");
+
+__device__ __forceinline__ CLds ccarve(char *smem, bool glibc, int lslots) {
+    using namespace lds_off;
     CLds L;
-    L.gev = reinterpret_cast<int2 *>(smem);
-    int *ip = reinterpret_cast<int *>(smem + sizeof(int2) * EVCAPC);
-    L.sidx = ip; ip += SCAPC;
-    L.rclist = ip; ip += RCCAP;
-    L.scal = ip; ip += 64;
-    L.dead = reinterpret_cast<unsigned *>(ip); ip += DEADW;
-    L.evoff = ip; ip += MAXG + 16;
-    L.bins = ip; ip += GBINS;
-    L.wtot = ip; ip += NW;
-    L.hist = ip; ip += 2 * nP; L.mloc = ip; ip += 2 * nP; L.mloc_stay = ip; ip += 2 * nP; L.cand_n = ip; ip += 2 * nP; L.total = ip; ip += nP; L.fcall = ip; ip += 2 * nP;
-    L.lcall = ip; ip += 2 * nP; L.nlv = ip; ip += nP; L.fie = ip; ip += nP;
-    L.queue = ip; ip += lslots > 0 ? lslots : QCAP; // (LDS-resident: every owned UE fits the queue)
-    L.gsum = ip; L.gpre = ip + GSCAP; L.gmask = reinterpret_cast<unsigned *>(ip + 2 * GSCAP); // only carved (and only touched) in glibc mode
+    L.gev = reinterpret_cast<int2 *>(smem + GEV);
+    L.sidx = reinterpret_cast<int *>(smem + SIDX);
+    L.rclist = reinterpret_cast<int *>(smem + RCLIST);
+    L.scal = reinterpret_cast<int *>(smem + SCAL);
+    L.dead = reinterpret_cast<unsigned *>(smem + DEAD);
+    L.evoff = reinterpret_cast<int *>(smem + EVOFF);
+    L.bins = reinterpret_cast<int *>(smem + BINS);
+    L.wtot = reinterpret_cast<int *>(smem + WTOT);
+    L.hist = reinterpret_cast<int *>(smem + HIST); L.mloc = reinterpret_cast<int *>(smem + MLOC);
+    L.mloc_stay = reinterpret_cast<int *>(smem + MLOC_STAY); L.cand_n = reinterpret_cast<int *>(smem + CAND_N);
+    L.total = reinterpret_cast<int *>(smem + TOTAL); L.fcall = reinterpret_cast<int *>(smem + FCALL);
+    L.lcall = reinterpret_cast<int *>(smem + LCALL); L.nlv = reinterpret_cast<int *>(smem + NLV); L.fie = reinterpret_cast<int *>(smem + FIE);
+    L.queue = reinterpret_cast<int *>(smem + QUEUE);
+    L.gsum = reinterpret_cast<int *>(smem + TAIL_G); L.gpre = L.gsum + GSCAP; L.gmask = reinterpret_cast<unsigned *>(L.gsum + 2 * GSCAP); // only touched in glibc mode
     (void)glibc;
     L.lrec = nullptr; L.lnd = nullptr; L.lcand = nullptr;
     if (lslots > 0) { // (never together with glibc mode)
-        ip += (4 - ((ip - reinterpret_cast<int *>(smem)) & 3)) & 3; // 16-byte alignment of the records
-        L.lrec = reinterpret_cast<int4 *>(ip); ip += 4 * lslots;
-        L.lnd = reinterpret_cast<unsigned *>(ip); ip += lslots;
-        L.lcand = reinterpret_cast<int2 *>(ip); ip += 2 * LCANDCAP;
+        L.lcand = reinterpret_cast<int2 *>(smem + LCAND);
+        L.lrec = reinterpret_cast<int4 *>(smem + TAIL_L);
+        L.lnd = reinterpret_cast<unsigned *>(smem + TAIL_L + 16 * lslots);
     }
     return L;
 }
@@ -798,7 +836,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     // block of the grid is resident at once (the engine keeps G x trials within the occupancy query's answer anyway)
     const int T = blockIdx.x / G, b = blockIdx.x % G;
     const TrialG P(params[T]);
-    const CLds L = ccarve(smem, P.nP, GLIBC, REC == REC_L16 ? lslots : 0);
+    const CLds L = ccarve(smem, GLIBC, REC == REC_L16 ? lslots : 0);
     const int tid = threadIdx.x;
     const int nUE = P.nUE, nP = P.nP, aT = P.aT;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
@@ -827,8 +865,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     }
     for (int k = tid; k < nP; k += WG_THREADS) {
         L.hist[k] = 0; L.mloc[k] = INT_MAX; L.mloc_stay[k] = INT_MAX; L.cand_n[k] = 0;
-        L.hist[nP + k] = 0; L.mloc[nP + k] = INT_MAX; L.mloc_stay[nP + k] = INT_MAX; L.cand_n[nP + k] = 0;
-        L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.fcall[nP + k] = INT_MAX; L.lcall[nP + k] = -1;
+        L.hist[NPC + k] = 0; L.mloc[NPC + k] = INT_MAX; L.mloc_stay[NPC + k] = INT_MAX; L.cand_n[NPC + k] = 0;
+        L.total[k] = 0; L.fcall[k] = INT_MAX; L.lcall[k] = -1; L.fcall[NPC + k] = INT_MAX; L.lcall[NPC + k] = -1;
         L.nlv[k] = 0; L.fie[k] = 0;
     }
     if (tid < 64) L.scal[tid] = tid == C_QEND ? QCAP : 0;
@@ -838,10 +876,11 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = P.stop;
     unsigned long long steps = 0;
-    int status = (lgroups > DEADW * 32 || (GLIBC && totgroups > GSCAP) || (REC == REC_L16 && lgroups * 64 > lslots)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (lgroups > DEADW * 32 || (GLIBC && totgroups > GSCAP) || (REC == REC_L16 && (lgroups * 64 > lslots || lslots > LQCAP)) || nP > NPC) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
     unsigned long long base = 0; // glibc: rand() calls consumed so far (relative to the stream window)
 #ifdef PRACH_STAMPS
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    unsigned long long fstamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = tprev;
     unsigned long long statN = 0, maxN = 0, statRC = 0, statNS = 0, maxNS = 0;
 #endif
 
@@ -850,7 +889,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     // grant could go to are left for phase B (compact_phase_a<true>).  Needs every owned UE to fit the event queue.
     const bool pipelined = !GLIBC && !P.dense_pass && P.pipeline && G > 1 && (REC == REC_L16 || lgroups * 64 <= QCAP);
     int ahead_for = -1; // subframe whose phase A has already run
-    auto parity_view = [&](const int par) { CLds V = L; V.hist = L.hist + par * nP; V.mloc = L.mloc + par * nP; V.mloc_stay = L.mloc_stay + par * nP; V.cand_n = L.cand_n + par * nP; return V; };
+    auto parity_view = [&](const int par) { CLds V = L; V.hist = L.hist + par * NPC; V.mloc = L.mloc + par * NPC; V.mloc_stay = L.mloc_stay + par * NPC; V.cand_n = L.cand_n + par * NPC; return V; };
 
     const unsigned rarlim_k = (unsigned)(P.maxRarWindow - 1) << PK_RAR_SHIFT;
 
@@ -866,8 +905,8 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         PRACH_G long long *const mbev = G > 1 ? mygr + 1 + nP : nullptr;
         // first / last caller tables are double-buffered by subframe parity: this subframe's resolver fills [A],
         // the pass (apply of the previous subframe) reads [B]
-        int *const fcallA = L.fcall + parity * nP, *const lcallA = L.lcall + parity * nP;
-        int *const fcallB = L.fcall + (parity ^ 1) * nP, *const lcallB = L.lcall + (parity ^ 1) * nP;
+        int *const fcallA = L.fcall + parity * NPC, *const lcallA = L.lcall + parity * NPC;
+        int *const fcallB = L.fcall + (parity ^ 1) * NPC, *const lcallB = L.lcall + (parity ^ 1) * NPC;
         const CLds Lc = parity_view(parity), Ln = parity_view(parity ^ 1); // per-bucket counts of this subframe / of the next one
         // An UL grant: the grant bit into the UE's record.  If phase A of subframe t+1 has already run it took a matched UE
         // (PEND_STAY) for steadily contending, counted it into its bucket and did not queue it: take it out again and queue
@@ -951,6 +990,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             else cluster_pass<2>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, base + actdraws);
             base += tot;
         } else {
+            FSTAMP(0); // loop head
             if (P.dense_pass) {
                 cluster_pass<0>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, 0ull);
             } else {
@@ -960,8 +1000,10 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 }
                 compact_phase_b<0>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag, 0ull);
             }
+            FSTAMP(1); // phase B body
         }
         __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
+        FSTAMP(2); // S1
         STAMP(0);
 
         // early leavers below this workgroup's lowest caller are the only ones a rank can need
@@ -979,7 +1021,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         }
         for (int k = tid; k < nP; k += WG_THREADS) { fcallB[k] = INT_MAX; lcallB[k] = -1; L.total[k] = 0; L.nlv[k] = 0; L.fie[k] = 0; } // ready for the gathers
         if (tid == 0) { L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP; } // (the queue has been consumed)
+        FSTAMP(3); // leaver filter + table reset
         __syncthreads(); // S2
+        FSTAMP(4); // S2
         int N;
         if (G == 1) {
             // one workgroup owns the whole trial: its histogram / lowest callers ARE the totals; events are in LDS
@@ -1007,6 +1051,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0;
             }
             STAMP(1);
+            FSTAMP(5); // publish stores
             // round 1: the bucket granules of every workgroup and, on the last wavefront, the headers.  The loads are issued,
             // then (pipelined) phase A of the NEXT subframe runs while they and the other workgroups' stores are in flight,
             // then every granule is checked and, if its tag is still the old one, re-read until it arrives.
@@ -1029,6 +1074,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             } else {
                 issue_loads();
             }
+            FSTAMP(6); // phase A ahead + round-1 loads issued
             auto take_bucket = [&](const int k, long long g_, const bool fetched) {
                 const int wg = k / nP, p = k - wg * nP;
                 if (!fetched || !granule_ok(g_, tag)) g_ = wait_granule(gr_of(C, parity, wg) + 1 + p, tag, &L.scal[C_STATUS]);
@@ -1061,7 +1107,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 if (l == 0) { L.scal[C_NSUCCTOT] = nsuc; L.scal[C_OVF] = ovf; }
             }
             if (ahead) ahead_for = t + 1;
+            FSTAMP(7); // round-1 granules taken
             __syncthreads(); // S3: totals, lowest definite callers, event offsets (and the next subframe's phase A)
+            FSTAMP(8); // S3
             STAMP(2);
             for (int k = tid; k < nP; k += WG_THREADS) { Lc.hist[k] = 0; Lc.mloc[k] = INT_MAX; Lc.mloc_stay[k] = INT_MAX; Lc.cand_n[k] = 0; } // this parity is used again in two subframes
             if (L.scal[C_STATUS] != PRACH_OK) { status = L.scal[C_STATUS]; time_exit = t; break; }
@@ -1077,7 +1125,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
                 classify_event(L, fcallA, k, ev);
             }
         }
+        FSTAMP(9); // round 2
         if (N > 0) __syncthreads(); // S4: events gathered and classified against the lowest DEFINITE callers (N is uniform)
+        FSTAMP(10); // S4
         STAMP(3);
 
         // ---- resolve (identical on every workgroup of the cluster) ----
@@ -1143,7 +1193,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { my_coll += __shfl_down(my_coll, d); my_txop += __shfl_down(my_txop, d); }
         if ((tid & 63) == 0) { if (my_coll) atomicAdd(&L.scal[C_COLL], my_coll); if (my_txop) atomicAdd(&L.scal[C_TXOP], my_txop); }
+        FSTAMP(11); // calls
         __syncthreads(); // S5: calls done; singles listed
+        FSTAMP(12); // S5
         STAMP(6);
         const int ns = L.scal[C_NS];
         if (ns > SCAPC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
@@ -1203,7 +1255,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         }
         grantCheck += ns;
         const int nsucc_tot = L.scal[C_NSUCCTOT];
+        FSTAMP(13); // grants
         if (Gr > 0 && ns > 0) __syncthreads(); // S6: the grants are in the records before the next pass reads them
+        FSTAMP(14); // S6
         STAMP(7);
 #ifdef PRACH_STAMPS
         if (tid == 0) { statNS += (unsigned long long)ns; if ((unsigned long long)ns > maxNS) maxNS = ns; }
@@ -1212,7 +1266,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }
     __syncthreads();
-    if (status == PRACH_OK && tlast >= 0) cluster_pass<3>(P, L, C, FM, L.fcall + (tlast & 1) * nP, L.lcall + (tlast & 1) * nP, tlast + 1, activeCheck, activeCheck, nullptr, 0u, 0ull);
+    if (status == PRACH_OK && tlast >= 0) cluster_pass<3>(P, L, C, FM, L.fcall + (tlast & 1) * NPC, L.lcall + (tlast & 1) * NPC, tlast + 1, activeCheck, activeCheck, nullptr, 0u, 0ull);
     __syncthreads();
 
     // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of the owned UEs
@@ -1264,6 +1318,7 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
         if (b == 0) {
 #ifdef PRACH_STAMPS
             for (int k = 0; k < 8; k++) o->stamps6[k] = stamps[k];
+            for (int k = 0; k < 16; k++) o->fstamps[k] = fstamps[k];
             o->dbg[0] = statN; o->dbg[1] = maxN; o->dbg[2] = statRC; o->dbg[3] = (statNS << 20) | maxNS;
 #endif
             o->time_exit = time_exit;
@@ -1276,8 +1331,9 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
 }
 
 size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots) {
-    return sizeof(int2) * EVCAPC + sizeof(int) * (SCAPC + RCCAP + 64 + DEADW + MAXG + 16 + GBINS + NW + 15 * nP + (lslots > 0 ? lslots : QCAP) + (glibc ? 4 * GSCAP : 0)) +
-           (lslots > 0 ? 16 + (size_t)lslots * 20 + sizeof(int2) * LCANDCAP : 0);
+    (void)nP; // the per-bucket tables have the fixed stride NPC
+    if (lslots > 0) return (size_t)lds_off::TAIL_L + (size_t)lslots * 20;
+    return (size_t)lds_off::TAIL_G + (glibc ? sizeof(int) * 4 * GSCAP : 0);
 }
 
 using cluster_kernel_t = void (*)(const TrialDev *, int, int);

@@ -217,7 +217,7 @@ static int lds_record_slots(const prach_engine *e, const prach_cfg *cfgs, const 
         const int groups = (cfgs[idx[k]].nUE + 63) / 64;
         lslots = std::max(lslots, (groups + G - 1) / G * 64);
     }
-    return cluster_kernel_lds_bytes(maxP, false, lslots) <= CLUSTER_LDS_LIMIT ? lslots : 0;
+    return (lslots <= CLUSTER_LQCAP && cluster_kernel_lds_bytes(maxP, false, lslots) <= CLUSTER_LDS_LIMIT) ? lslots : 0;
 }
 
 static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, prach_result *results,
@@ -392,6 +392,12 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
                          dr.stamps6[0] / (double)dr.steps, dr.stamps6[1] / (double)dr.steps, dr.stamps6[2] / (double)dr.steps, dr.stamps6[3] / (double)dr.steps,
                          dr.stamps6[4] / (double)dr.steps, dr.stamps6[5] / (double)dr.steps, dr.stamps6[6] / (double)dr.steps, dr.stamps6[7] / (double)dr.steps,
                          dr.dbg[0] / (double)dr.steps, dr.dbg[1], dr.dbg[2] / (double)dr.steps, (dr.dbg[3] >> 20) / (double)dr.steps, dr.dbg[3] & 0xfffff);
+        if (std::getenv("PRACH_PRINT_STAMPS")) {
+            static const char *const nm[16] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "aheadA", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "-"};
+            std::fprintf(stderr, "[prach fine stamps/step]");
+            for (int q = 0; q < 15; q++) std::fprintf(stderr, " %s=%.0f", nm[q], dr.fstamps[q] / (double)dr.steps);
+            std::fprintf(stderr, "\n");
+        }
         if (dr.status != PRACH_OK) continue;
         // totalDelay is a FLOAT running sum in index order (Beta.c:186,193): exact in integer
         // arithmetic while it stays below 2^24, otherwise replay the float additions on the host.

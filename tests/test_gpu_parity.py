@@ -401,6 +401,31 @@ def test_cli_results_csv(pkg, tmp_path):
     assert subprocess.run([pkg.CLI_PATH, "--csv", "x.csv"], capture_output=True).returncode == 255  # needs --program beta
 
 
+def test_cli_results_csv_vs_reference_script(pkg, tmp_path):
+    """The published experiment end to end on the GPU: `prach_sim --program beta -g 12 -t 100 --rng philox --csv` — 1000 trials
+    in one call — against the results.csv the reference's own AveragePerformance.py wrote from the oracle's files for the
+    same 1000 (seed, nUE) trials (tests/golden/results_csv.json).  The sixth column is the reference's wall clock: the
+    first five must be byte-identical."""
+    import base64
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "results_csv.json")))
+    want = base64.b64decode(fx["results_csv_b64"]).split(b"\r\n")[:10]
+    (tmp_path / "BasicBetaSimulationResults").mkdir()
+    csvf = tmp_path / "results.csv"
+    p = subprocess.run([pkg.CLI_PATH, "--program", "beta", "-g", "12", "-t", "100", "--rng", "philox", "--logs", "0", "--out", str(tmp_path),
+                        "--csv", str(csvf)], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = csvf.read_bytes().split(b"\r\n")
+    assert len(got) == 11 and got[10] == b""
+    for g, w in zip(got[:10], want):
+        assert g.split(b",")[:5] == w.split(b",")[:5], (g, w)
+    # and the per-seed files are the oracle's (first five lines)
+    for key in ("0_10000", "57_60000", "99_100000"):
+        s_, n_ = key.split("_")
+        txt = (tmp_path / "BasicBetaSimulationResults" / f"{s_}_54_{n_}_Results.txt").read_text()
+        assert txt.split("\n")[:5] == fx["results_txt"][key].split("\n")[:5]
+
+
 def test_sharded_sweep_driver_two_ranks(pkg, ob, tmp_path):
     """sweep.py (BASELINE config 5 shape) with 2 ranks rehearsed on one GPU (gloo): sharding + ONE all-reduce +
     row gather + results.csv; the aggregate equals the oracle's trial by trial."""

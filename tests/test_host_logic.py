@@ -122,6 +122,27 @@ def test_cli_usage_on_unknown_flag(pkg):
     assert p.returncode == 255
 
 
+def test_results_csv_matches_reference_script(pkg):
+    """PINNED by the reference's own post-processor: tests/golden/results_csv.json holds 1000 Results.txt texts (oracle,
+    Beta.c program, 12 grants, seeds 0..99 x nUE 10k..100k) and the bytes of the results.csv that
+    /root/reference/AveragePerformance.py — executed unmodified, by path, in a scratch directory
+    (tests/golden/make_results_csv.py) — wrote from them.  prach_results_csv_accumulate / prach_results_csv_row
+    (AveragePerformance.py:10-24 in host C) must reproduce those bytes."""
+    import base64
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "results_csv.json")))
+    want = base64.b64decode(fx["results_csv_b64"])
+    rows = [[fx["results_txt"][f"{s}_{n}"] for s in fx["seeds"]] for n in fx["points"]]
+    assert len(rows) == 10 and all(len(r) == 100 for r in rows)
+    got = pkg.results_csv(rows)
+    assert got == want
+    assert want.count(b"\r\n") == 10 and want.startswith(b"10000.0,100.0,10000.0,")
+    # (the published file of the reference's own 100-seed run, results.csv:10, reads 100000.0,18.99,18989.29,5.76,96.001,...)
+    last = want.split(b"\r\n")[9].split(b",")
+    assert abs(float(last[1]) - 18.99) < 0.05 and abs(float(last[4]) - 96.0) < 0.1
+
+
 def test_results_csv_matches_numpy_csv_writer(pkg, tmp_path):
     """results.csv rows == what AveragePerformance.py's arithmetic and csv.writer produce
     (sequential double sum in seed order, /nseeds, np.around(.,3), float repr, CRLF)."""
