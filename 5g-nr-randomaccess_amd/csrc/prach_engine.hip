@@ -49,6 +49,7 @@ struct prach_engine {
 #else
     int64_t opt_lds_records = 1;   // 0: clusters keep their UE records in global memory (diagnostic)
 #endif
+    int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
     int num_cus = 256;
 };
 
@@ -78,7 +79,7 @@ size_t mbox_bytes(const prach_cfg &c, int G, int &evw, int &mbstride) {
     evw = 0; mbstride = 0;
     if (G <= 0) return 0;
     const size_t n = (size_t)c.nUE;
-    evw = G == 1 ? 4096 : 512;
+    evw = G == 1 ? 4096 : CLUSTER_EVW;
     const size_t lgroups = ((n + 63) / 64 + (size_t)G - 1) / (size_t)G;
     mbstride = (int)align_up((size_t)2 * (1 + c.nPreamble + evw + (lgroups + 1) / 2), 4); // 8-byte granules: header, buckets, events, (glibc) group draw counts
     if (c.variant == PRACH_VARIANT_NOMA_C) mbstride = (int)align_up((size_t)2 * (1 + 6 * c.nPreamble), 4); // header + 6 x nP bins
@@ -219,6 +220,10 @@ static int lds_record_slots(const prach_engine *e, const prach_cfg *cfgs, const 
     }
     return (lslots <= CLUSTER_LQCAP && cluster_kernel_lds_bytes(maxP, false, lslots) <= CLUSTER_LDS_LIMIT) ? lslots : 0;
 }
+// ... on the lean kernel (prach_lcluster.hip): pipelined compacted pass only, nPreamble <= 64
+static bool use_fast_kernel(const prach_engine *e, int lslots, int maxP) {
+    return lslots > 0 && e->opt_fast && e->opt_pipeline && maxP <= lcluster_max_preambles() && lcluster_kernel_lds_bytes(lslots) <= CLUSTER_LDS_LIMIT;
+}
 
 static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, prach_result *results,
                      prach_ue_log *const *ue_logs, int attempt, int G, double &kernel_ms, double &upload_ms) {
@@ -344,9 +349,10 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             compact = (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 64 < 63000;
         }
         const int lslots = lds_record_slots(e, cfgs, idx, m, G, maxP);
-        const int rec_mode = lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16);
+        const int rec_mode = use_fast_kernel(e, lslots, maxP) ? CLUSTER_REC_LFAST : (lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16));
         e->last.rec_mode = rec_mode;
-        HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, e->stream));
+        if (rec_mode == CLUSTER_REC_LFAST) HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, e->stream));
+        else HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, e->stream));
     }
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(A), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
@@ -593,6 +599,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "resident") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_resident = value; return PRACH_OK; }
     if (std::strcmp(key, "host_threads") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_host_threads = value; return PRACH_OK; }
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }
 

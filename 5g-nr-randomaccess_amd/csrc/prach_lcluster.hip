@@ -1,0 +1,983 @@
+// prach_lcluster.hip — the HEADLINE kernel: one Philox trial on a cluster of G workgroups whose UE state is resident in LDS.
+//
+// Same parallel-exact decomposition as prach_cluster.hip (static interleaved ownership of 64-UE groups, one
+// granule exchange per subframe, set-wise ranks, compacted two-phase pass, phase A of subframe t+1 inside the exchange of
+// subframe t) — and the same results, bit for bit (tests/test_gpu_parity.py runs both against the oracle).  What differs is
+// how it is written.  A subframe of a single trial is a CHAIN of short dependent phases in which every wavefront executes a
+// few hundred instructions; one wavefront issues a vector instruction every 4-8 cycles (MI355X_MICROARCH.md, "vector-
+// instruction ISSUE cost"), so the subframe time is the number of instructions on that chain, not bytes and not lanes.  The
+// general kernel carried ~250 spilled scalar registers through that chain (v_readlane / v_writelane on every phase boundary),
+// 64-bit mailbox address arithmetic per granule, run-time LDS table offsets and loops around single-trip work.  Here:
+//   * every LDS table sits at a COMPILE-TIME offset (bucket tables have the fixed stride NPCL = 64: nPreamble <= 64, the
+//     reference's 54 / 64); an LDS address is an instruction immediate, not a live register;
+//   * each thread's role in the exchange (which granules it loads, which bucket it publishes) is computed ONCE before the
+//     step loop and kept in vector registers as 32-bit offsets from the mailbox base;
+//   * the hot record (16 B) and the Philox draw index of every owned UE live in LDS for the whole trial (no L2 round trip
+//     for a record, a draw index or an early-leaver candidate anywhere in the step loop); finished groups are a per-wavefront
+//     register bit mask; subframe bookkeeping (t mod 5, t mod accessTime, the arrival table) is incremental scalar state;
+//   * only the Philox path, only clusters (G > 1), only the pipelined compacted pass: the engine falls back to
+//     prach::cluster_kernel for everything else (glibc streams, one workgroup per trial, nPreamble > 64, more owned UEs than
+//     LDS holds, diagnostic options).
+// Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351.
+#include "prach_device.h"
+#include "prach_device_fn.h"
+#include <limits.h>
+
+namespace prach {
+
+namespace {
+
+#ifdef PRACH_STAMPS
+#define LSTAMP(k)                                                                                      \
+    do {                                                                                               \
+        if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); fstamps[k] += now_ - fprev; fprev = now_; } \
+    } while (0)
+#else
+#define LSTAMP(k) do { } while (0)
+#endif
+
+constexpr int NPCL = 64;     // stride of the per-bucket tables (nPreamble <= 64)
+constexpr int LEV = 4096;    // gathered events per subframe
+constexpr int LSC = 2048;    // singleton callers per subframe
+constexpr int LCC = 1024;    // early-leaver candidates per workgroup and subframe
+constexpr int LQ = CLUSTER_LQCAP; // event queue = at most every owned UE slot
+constexpr int LGB = 1024;    // grant selection bins
+constexpr int LEPF = 32;     // event granules of every mailbox fetched together with the bucket granules (more: a second round)
+constexpr int LRQ = 1024;    // UEs per subframe whose next two Philox draws are recomputed ahead (more: drawn in place)
+constexpr unsigned ND_READY = 0x80000000u; // lnd[slot] bit 31: ldraw[slot] holds draws nd, nd + 1 of this UE
+constexpr unsigned LSPIN = 1u << 22;
+constexpr int EVL_CALLER = 1, EVL_RESETCAND = 2, EVL_RJOIN = 3, EVL_LEAVER = 4; // (= prach_cluster.hip's EVC_*)
+
+// scalars in LDS
+enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_STATUS, S_NEV, S_NCAND, S_OVF, S_NSUCCTOT, S_NTOT, S_PTC, S_FC, S_SUMT = 16,
+       S_ND = 18, S_NCROSS = 20, S_QN = 22, S_NRQ = 23, S_NREM = 24 };
+
+// ---- LDS layout: byte offsets, all compile-time -------------------------------------------------------------------
+namespace lo {
+constexpr int GEV = 0;                          // int2 [LEV] gathered events
+constexpr int SIDX = GEV + 8 * LEV;             // int [LSC]
+constexpr int RCL = SIDX + 4 * LSC;             // int [RCCAP]
+constexpr int SCAL = RCL + 4 * RCCAP;           // int [64]
+constexpr int EVOFF = SCAL + 4 * 64;            // int [64 + 16]
+constexpr int BINS = EVOFF + 4 * 80;            // int [LGB]
+constexpr int WTOT = BINS + 4 * LGB;            // int [NW]
+constexpr int PAR = WTOT + 4 * NW;              // per subframe parity: HIST, MLOC, MLOCS, CANDN, each [NPCL]
+constexpr int PARSZ = 4 * 4 * NPCL;
+constexpr int P_HIST = 0, P_MLOC = 4 * NPCL, P_MLOCS = 8 * NPCL, P_CANDN = 12 * NPCL;
+constexpr int RB = PAR + 2 * PARSZ;             // per subframe parity, the resolver's tables: FCALL, LCALL, TOTAL, NLV, FIE, each [NPCL]
+constexpr int RBSZ = 5 * 4 * NPCL;
+constexpr int FCALL = RB, LCALL = RB + 4 * NPCL, TOTAL = RB + 8 * NPCL, NLV = RB + 12 * NPCL, FIE = RB + 16 * NPCL; // (+ parity * RBSZ)
+constexpr int QUEUE = RB + 2 * RBSZ;            // int [LQ] slots of the UEs that have an event in this subframe
+constexpr int LCAND = QUEUE + 4 * LQ;           // int2 [LCC]
+constexpr int RQ = BINS;                        // int [LRQ] refill list (phase B .. round 1; BINS is only used by the grant selection)
+constexpr int TAIL = LCAND + 8 * LCC;           // int4 lrec[lslots]; int2 ldraw[lslots]; unsigned lnd[lslots]
+static_assert(LRQ <= LGB, "the refill list shares the grant bins");
+static_assert(SIDX % 16 == 0 && TAIL % 16 == 0 && LCAND % 8 == 0, "alignment");
+} // namespace lo
+
+#define LI(off) (reinterpret_cast<int *>(smem + (off)))
+#define LU(off) (reinterpret_cast<unsigned *>(smem + (off)))
+#define LI2(off) (reinterpret_cast<int2 *>(smem + (off)))
+
+// ---- exchange granules (as in prach_cluster.hip): ONE naturally aligned 8-byte write-through store {20-bit value | tag[11:0]}
+// {20-bit value | tag[15:12]}; the consumer re-reads until the tag (subframe + 1) matches: no flag, no fence (guide G16 / R2)
+constexpr unsigned GRL_NONE = 0xFFFFFu;
+__device__ __forceinline__ long long lmk(unsigned lo20, unsigned hi20, unsigned tag) {
+    const unsigned w0 = (lo20 & 0xFFFFFu) | ((tag & 0xFFFu) << 20), w1 = (hi20 & 0xFFFFFu) | (((tag >> 12) & 0xFu) << 20);
+    return (long long)(((unsigned long long)w1 << 32) | w0);
+}
+__device__ __forceinline__ bool lok(long long g, unsigned tag) {
+    const unsigned w0 = (unsigned)g, w1 = (unsigned)((unsigned long long)g >> 32);
+    return (w0 >> 20) == (tag & 0xFFFu) && ((w1 >> 20) & 0xFu) == ((tag >> 12) & 0xFu);
+}
+__device__ __forceinline__ long long lld(const PRACH_G long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lst(PRACH_G long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long lwait(const PRACH_G long long *p, unsigned tag, char *smem) {
+    long long g = lld(p);
+    unsigned spins = 0;
+    while (!lok(g, tag)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > LSPIN) { LI(lo::SCAL)[S_STATUS] = PRACH_ERR_TIMEOUT; break; } // peer not resident? the engine reruns the trial
+        g = lld(p);
+    }
+    return g;
+}
+
+// per-trial constants of the step loop (wave-uniform)
+struct LK {
+    int nUE, nP, aT, maxRar, maxMsg2, variant, b, G;
+    bool withnoma;
+    unsigned seed_lo, seed_hi, rarlim;
+    FastMod fmP, fmB, fmA, fm5;
+    PRACH_G int *ptc, *ftt, *stt, *fcnt;
+};
+
+__device__ __forceinline__ int l_idx_of(const LK &K, const int slot) { return (K.b + K.G * (slot >> 6)) * 64 + (slot & 63); }
+
+// contending with a RAR window that stays open (prach_cluster.hip light_case)
+__device__ __forceinline__ bool l_light(const unsigned pk, const int rx, const int rz, const int t, const unsigned rarlim) {
+    const unsigned pg = pk >> PK_PEND_SHIFT;
+    const bool contend = (pk & 3u) == (unsigned)ACT_M1 && (pk & (0xffu << PK_PRE_SHIFT)) != 0u && rz <= t;
+    const int age = pg == (unsigned)PEND_STAY ? t - 1 - rx : 0;
+    const unsigned rarnow = (pk & (0xffu << PK_RAR_SHIFT)) + ((unsigned)age << PK_RAR_SHIFT);
+    return pg < 3u && contend && rarnow < rarlim;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The full per-UE body for one queued UE per lane (prach_cluster.hip ue_step<0>: deferred outcome of subframe t-1, activation,
+// selectPreamble / requestResourceAllocation on own state, bucket bookkeeping, special events).  pc: byte offset of this
+// subframe's parity block; fb: byte offset of the previous subframe's first / last caller tables inside FCALL / LCALL.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsigned *lnd, const int2 *ldraw, const int pc, const int fb, const int t, const int prevAC,
+                                       PRACH_G long long *mbev, const unsigned tag, const int lane, const int i, const int slot, const bool valid, const int4 r,
+                                       unsigned ndc, int &c_succ, int &c_contf) {
+    const int aT = K.aT, nUE = K.nUE;
+    const bool withnoma = K.withnoma;
+    const int tp = t - 1;
+    const int tmod = fastmod(t, K.fmA);
+    const int *const fcall = LI(lo::FCALL + fb), *const lcall = LI(lo::LCALL + fb);
+    int *const hist = LI(lo::PAR + pc + lo::P_HIST), *const mloc = LI(lo::PAR + pc + lo::P_MLOC), *const candn = LI(lo::PAR + pc + lo::P_CANDN);
+    bool nd_dirty = false, dirty = false;
+    bool rdy = (ndc & ND_READY) != 0u;
+    ndc &= ~ND_READY;
+    UeState u = unpack(r);
+
+    // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
+    if (u.pend != PEND_NONE) {
+        if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; } // (the record dates from subframe u.tx: compact phase A)
+        if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
+            u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
+            if (u.pend == PEND_RESET) u.bo = 0;
+        } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
+            u.tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
+        } else if (u.pend == PEND_RESET) {
+            const int q = u.bo, tmp = u.tx;
+            const int bumped = fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
+            const int x = slot_align_fm(tp + bumped + tmp, K.fmA);
+            if (x == tp) { u.bo = 0; u.tx = tp + 1; }
+            else { u.tx = x; u.bo = x; }
+        } else if (u.pend == PEND_PASSIVE) {
+            if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
+        } else { // PEND_RJOIN
+            if (lcall[u.pre - 1] > i) u.tx = tp + 1;
+        }
+        u.pend = PEND_NONE;
+        dirty = true;
+    }
+    // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
+    if (valid && i >= prevAC) {
+        u.act = ACT_M1; u.tx = t + 1; u.tb = t;
+        K.ftt[i] = t + 1;
+        // (activateUEs' two draws, WithNOMA:393-394, are never looked at: a WithNOMA UE's draw index STARTS at 2)
+        dirty = true;
+    }
+    const bool isM1 = u.act == ACT_M1;
+    const int nb = now_backoff(u.bo, t);
+    const bool firstsel = isM1 && u.pre == 0;
+    const bool contend = isM1 && u.pre != 0 && nb <= 0;
+    const bool expire = contend && (u.rar + 1 >= K.maxRar);
+    const bool reset = expire && u.mrc >= K.maxMsg2;
+    const bool retx = expire && !reset;
+    const bool m3due = u.act == ACT_M3 && u.tx == t;
+    const bool m3first = m3due && u.conn == 0, m3to = m3due && u.conn != 0;
+    const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
+
+    // The next two draws of a UE (Philox counters nd, nd + 1) were computed AHEAD, off the subframe's critical chain (refill in
+    // the exchange window), and wait in LDS; a UE whose refill did not fit the list draws in place.
+    int d1 = 0, d2 = 0;
+    if (__any(need > 0)) {
+        const unsigned k = ndc;
+        if (need > 0 && rdy) { const int2 dd = ldraw[slot]; d1 = dd.x; d2 = dd.y; }
+        if (__any(need > 0 && !rdy)) {
+            const int e1 = philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, k, (unsigned)nUE, (unsigned)K.variant);
+            const int e2 = philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, (unsigned)K.variant);
+            if (!rdy) { d1 = e1; d2 = e2; }
+        }
+        if (need > 0) {
+            ndc = k + (unsigned)need; nd_dirty = true; rdy = false;
+            const unsigned long long rm = __ballot(true); // (only lanes with need > 0 are here)
+            int base = 0;
+            const int first = __builtin_ctzll(rm);
+            if (lane == first) base = atomicAdd(&LI(lo::SCAL)[S_NRQ], __popcll(rm));
+            base = __shfl(base, first);
+            const int rs = base + __popcll(rm & lanemask_lt(lane));
+            if (rs < LRQ) LI(lo::RQ)[rs] = slot;
+        }
+    }
+
+    // ---- selectPreamble / requestResourceAllocation on own state ----
+    const int oldp = u.pre - 1;
+    const bool member_pre = isM1 && u.tx == t && u.pre != 0; // matched by a preambleCollision scan right now
+    int evtype = 0, evp = 0, evq = 0;
+    bool eclass = false; // pre-member that leaves its bucket at its own turn without calling on it
+    if (firstsel) { // Beta.c:231-239
+        u.pre = fastmod(d1, K.fmP) + 1; u.rar = 0; u.mrc = 0; u.bo = 0;
+        K.ptc[i] = 1;
+        if (withnoma) K.fcnt[i] = 0;
+        if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVL_CALLER; evp = u.pre - 1; }
+        dirty = true;
+    } else if (isM1 && u.pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
+        if (member_pre) { u.pend = withnoma ? PEND_STAY : PEND_PASSIVE; dirty = true; } // WithNOMA:310 calls anyway
+    } else if (contend) {
+        u.rar++; // Beta.c:245
+        dirty = true;
+        if (reset) { // Beta.c:250-281
+            if (withnoma) { c_contf++; gadd(&K.fcnt[i], 1); }
+            const int newp = fastmod(d1, K.fmP);
+            const int tmp = fastmod(d2, K.fmB);
+            u.rar = 0; u.mrc = 0; u.tb = t;
+            K.ptc[i] = 1; K.ftt[i] = t + 1;
+            u.pre = newp + 1;
+            if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
+                u.pend = PEND_RESET; u.tx = tmp; u.bo = oldp;
+                eclass = true;
+                if (tmp == 0 && aT > 1 && tmod == 1) { evtype = EVL_RESETCAND; evp = newp; evq = oldp; }
+            } else {
+                u.tx = slot_align_fm(u.tx + tmp, K.fmA);
+                u.bo = enc_backoff(u.tx - t, t);
+                if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVL_CALLER; evp = newp; }
+            }
+        } else if (retx) { // Beta.c:282-308
+            u.rar = 0; u.mrc++;
+            gadd(&K.ptc[i], 1);
+            const int tmp = fastmod(d1, K.fmB);
+            u.tx = slot_align_fm(t + tmp, K.fmA);
+            u.bo = enc_backoff(u.tx - t, t);
+            K.stt[i] = u.tx;
+            if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVL_CALLER; evp = oldp; } // the "late joiner"
+            else if (member_pre) eclass = true;
+        } else if (member_pre) {
+            u.pend = PEND_STAY;
+        }
+    } else if (m3first) { // Beta.c:372-383
+        u.conn = 1;
+        const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
+        if ((double)pf > 0.1) { u.act = ACT_DONE; u.tb = (t - u.tb) + 6; c_succ++; }
+        else { u.conn = 2; u.tx += 48; }
+        dirty = true;
+    } else if (m3to) { // Msg3 timeout, Beta.c:384-410
+        c_contf++;
+        const int tmp = fastmod(d1, K.fmB);
+        u.tx = slot_align_fm(u.tx + tmp, K.fm5); // hard-coded accessTime = 5, Beta.c:389
+        u.act = ACT_M1;
+        u.bo = enc_backoff(u.tx - t, t);
+        u.pre = fastmod(d2, K.fmP) + 1;
+        u.tb = t; u.rar = 0; u.mrc = 0; u.conn = 0;
+        if (withnoma) gadd(&K.fcnt[i], 1);
+        if (u.tx == t) { u.pend = PEND_RJOIN; evtype = EVL_RJOIN; evp = u.pre - 1; }
+        dirty = true;
+    }
+
+    // ---- bucket bookkeeping (workgroup-level LDS atomics) ----
+    if (member_pre) atomicAdd(&hist[oldp], 1);
+    if (u.pend == PEND_STAY) { if (__atomic_load_n(&mloc[oldp], __ATOMIC_RELAXED) > i) atomicMin(&mloc[oldp], i); }
+    if (evtype == EVL_CALLER) atomicMin(&mloc[evp], i);
+    {
+        const unsigned long long em = __ballot(evtype != 0);
+        if (em) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&LI(lo::SCAL)[S_NEV], __popcll(em));
+            base = __shfl(base, 0);
+            if (evtype != 0) {
+                const int es = base + __popcll(em & lanemask_lt(lane));
+                const int ispre = (evtype == EVL_CALLER) ? (member_pre && oldp == evp) : (evtype == EVL_RESETCAND ? (evp == evq) : 0);
+                const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
+                if (es < CLUSTER_EVW) lst(mbev + es, lmk((unsigned)i, (unsigned)info, tag));
+            }
+        }
+        const unsigned long long cm = __ballot(eclass);
+        if (cm) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&LI(lo::SCAL)[S_NCAND], __popcll(cm));
+            base = __shfl(base, 0);
+            if (eclass) {
+                const int cs = base + __popcll(cm & lanemask_lt(lane));
+                if (cs < LCC) LI2(lo::LCAND)[cs] = make_int2(i, oldp);
+                else LI(lo::SCAL)[S_STATUS] = PRACH_ERR_INTERNAL; // (engine: exact rerun on the general kernels)
+                atomicAdd(&candn[oldp], 1);
+            }
+        }
+    }
+    if (nd_dirty) lnd[slot] = ndc | (rdy ? ND_READY : 0u);
+    if (dirty) lrec[slot] = pack(u);
+}
+
+// One gathered event against the lowest DEFINITE caller of every bucket (complete after round 1).
+__device__ __forceinline__ void l_classify(char *smem, const int fa, const int k, const int2 ev) {
+    const int *const fcallA = LI(lo::FCALL + fa);
+    const int type = ev.y & 7, p = (ev.y >> 4) & 0xff;
+    if (type == EVL_RESETCAND) {
+        if (fcallA[(ev.y >> 12) & 0xff] < ev.x) LI2(lo::GEV)[k].y = 0; // bumped on its old bucket before its turn: cannot re-join
+        else { const int s = atomicAdd(&LI(lo::SCAL)[S_NRC], 1); if (s < RCCAP) LI(lo::RCL)[s] = k; }
+    } else if (type == EVL_RJOIN) {
+        atomicAdd(&LI(lo::SCAL)[S_NRJ], 1);
+    } else if (type == EVL_LEAVER) {
+        if (ev.x < fcallA[p]) atomicAdd(&LI(lo::NLV + fa)[p], 1);
+    } else if (type == EVL_CALLER) {
+        if (ev.x == fcallA[p]) LI(lo::FIE + fa)[p] = 1;
+    }
+}
+
+// Reset-cycle re-join candidates, strictly in index order, by ONE wavefront with the first-caller table in registers
+// (lane = bucket; nPreamble <= 64).  prach_cluster.hip resolve_reset_candidates.
+__device__ __forceinline__ void l_resolve_reset_candidates(char *smem, const int fa, const int nrc_in, const int nP) {
+    const int lane = threadIdx.x & 63;
+    const int n = __builtin_amdgcn_readfirstlane(nrc_in);
+    int *const fcall = LI(lo::FCALL + fa);
+    int *const rcl = LI(lo::RCL), *const sidx = LI(lo::SIDX);
+    int2 *const gev = LI2(lo::GEV);
+    int f0 = lane < nP ? fcall[lane] : INT_MAX;
+    for (int c = lane; c < n; c += 64) { // rank-sort the candidate list by UE index into SIDX (free at this point of the subframe)
+        const int myidx = gev[rcl[c]].x;
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += gev[rcl[j]].x < myidx ? 1 : 0;
+        sidx[rank] = rcl[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int base = 0; base < n; base += 64) {
+        const int m = min(64, n - base);
+        int es = 0, cidx = 0, cinfo = 0;
+        if (lane < m) { es = sidx[base + lane]; const int2 e = gev[es]; cidx = e.x; cinfo = e.y; }
+        int cancelled = 0;
+        for (int s_ = 0; s_ < m; s_++) {
+            const int idx = __builtin_amdgcn_readlane(cidx, s_), info = __builtin_amdgcn_readlane(cinfo, s_);
+            const int p = (info >> 4) & 0xff, q = (info >> 12) & 0xff;
+            if (__builtin_amdgcn_readlane(f0, q & 63) < idx) { // bumped before its turn: does not re-join
+                if (lane == s_) cancelled = 1;
+            } else if (idx < __builtin_amdgcn_readlane(f0, p & 63)) { // its call becomes the first one on p
+                if (lane == (p & 63)) f0 = idx;
+            }
+        }
+        if (lane < m && cancelled) gev[es].y = 0;
+    }
+    if (lane < nP) fcall[lane] = f0;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
+    const TrialDev *const PD = params + T;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LK K;
+    K.nUE = PD->nUE; K.nP = PD->nP; K.aT = PD->aT; K.maxRar = PD->maxRarWindow; K.maxMsg2 = PD->maxMsg2; K.variant = PD->variant;
+    K.b = b; K.G = G;
+    K.withnoma = K.variant == PRACH_VARIANT_WITHNOMA_C;
+    K.seed_lo = PD->seed_lo; K.seed_hi = PD->seed_hi;
+    K.rarlim = (unsigned)(K.maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
+    K.fmP = make_fastmod(K.nP); K.fmB = make_fastmod(PD->backoff); K.fmA = make_fastmod(K.aT); K.fm5 = make_fastmod(5);
+    K.ptc = (PRACH_G int *)PD->ptc; K.ftt = (PRACH_G int *)PD->ftt; K.stt = (PRACH_G int *)PD->stt; K.fcnt = (PRACH_G int *)PD->fcnt;
+    const int nUE = K.nUE, nP = K.nP, aT = K.aT;
+    const int stop = PD->stop, nGrantUL = PD->nGrantUL, binshift = PD->binshift;
+    const PRACH_G int *const sched = (const PRACH_G int *)PD->sched;
+    const bool withnoma = K.withnoma;
+
+    int4 *const lrec = reinterpret_cast<int4 *>(smem + lo::TAIL);
+    int2 *const ldraw = reinterpret_cast<int2 *>(smem + lo::TAIL + 16 * lslots);
+    unsigned *const lnd = reinterpret_cast<unsigned *>(smem + lo::TAIL + 24 * lslots);
+    int *const scal = LI(lo::SCAL);
+    int *const queue = LI(lo::QUEUE);
+    int2 *const gev = LI2(lo::GEV);
+
+    const int totgroups = (nUE + 63) >> 6;
+    const int lgroups = (totgroups + G - 1) / G; // local groups of any workgroup (upper bound)
+
+    // mailboxes: [2 parities][G workgroups][mbs granules]: header, nP bucket granules, CLUSTER_EVW event granules
+    const unsigned mbs = (unsigned)PD->mbstride >> 1; // granules per mailbox
+    PRACH_G long long *const mbox = (PRACH_G long long *)PD->mbox;
+    const unsigned parstride = (unsigned)G * mbs;       // granules per parity
+    // this thread's fixed roles in the exchange, as granule offsets inside a parity block
+    unsigned r1off[3];
+    int r1p[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) { // round 1: up to 3072 bucket granules (G = 48 x 64 preambles); more: the tail loop below
+        const int k = tid + u * WG_THREADS;
+        const int wg = k / max(nP, 1), p = k - wg * nP;
+        r1p[u] = k < G * nP ? p : -1;
+        r1off[u] = (unsigned)wg * mbs + 1u + (unsigned)p;
+    }
+    unsigned r2off[2]; // round 1 also fetches the first LEPF event granules of every mailbox: this thread's (workgroup, slot)
+    int r2wg[2], r2es[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k = tid + u * WG_THREADS;
+        r2wg[u] = k < G * LEPF ? k / LEPF : -1;
+        r2es[u] = k % LEPF;
+        r2off[u] = (unsigned)(k / LEPF) * mbs + 1u + (unsigned)nP + (unsigned)(k % LEPF);
+    }
+    const int hl = tid - (WG_THREADS - 64);            // the last wavefront reads the headers: lane = workgroup
+    const unsigned hoff = (unsigned)max(hl, 0) * mbs;
+    const unsigned myoff = (unsigned)b * mbs;           // own mailbox
+
+    // calloc + initialUE (Beta.c:78-83) for the groups this workgroup owns
+    const unsigned nd0 = K.withnoma ? 2u : 0u; // activateUEs draws twice before the first preamble draw (WithNOMA:393-394)
+    for (int x = tid; x < lslots; x += WG_THREADS) {
+        lrec[x] = make_int4(-1, 0, 0, 0); lnd[x] = nd0; // (every slot, also past the last UE)
+        if (x < lgroups * 64) {
+            const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
+            if (g < totgroups && i < nUE) {
+                K.ptc[i] = 0; K.ftt[i] = 0; K.stt[i] = 0; K.fcnt[i] = 0;
+                ldraw[x] = make_int2(philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd0, (unsigned)K.nUE, (unsigned)K.variant),
+                                     philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd0 + 1u, (unsigned)K.nUE, (unsigned)K.variant));
+                lnd[x] = nd0 | ND_READY;
+            }
+        }
+    }
+    if (tid < NPCL) {
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            LI(lo::PAR + par * lo::PARSZ + lo::P_HIST)[tid] = 0; LI(lo::PAR + par * lo::PARSZ + lo::P_MLOC)[tid] = INT_MAX;
+            LI(lo::PAR + par * lo::PARSZ + lo::P_MLOCS)[tid] = INT_MAX; LI(lo::PAR + par * lo::PARSZ + lo::P_CANDN)[tid] = 0;
+            LI(lo::FCALL + par * lo::RBSZ)[tid] = INT_MAX; LI(lo::LCALL + par * lo::RBSZ)[tid] = -1;
+            LI(lo::TOTAL + par * lo::RBSZ)[tid] = 0; LI(lo::NLV + par * lo::RBSZ)[tid] = 0; LI(lo::FIE + par * lo::RBSZ)[tid] = 0;
+        }
+    }
+    if (tid < 64) scal[tid] = 0;
+    __syncthreads();
+
+    int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
+    unsigned long long steps = 0;
+    int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || G > 64 || lgroups > 64 * NW) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    unsigned long long deadmask = 0; // bit m: this wavefront's m-th group (local group w + NW * m) is finished for good
+    int t5 = 0, tA = 0, slotA = 0;   // t mod 5, t mod accessTime, t / accessTime: kept incrementally
+    int acNext = sched[0];           // arrival table entry of the NEXT access slot, fetched one slot ahead
+#ifdef PRACH_STAMPS
+    unsigned long long fstamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
+    unsigned long long dstat[4] = {0, 0, 0, 0}; // thread 0: sum of queue lengths, round-1 bucket / event granules read again, refills
+#define LSTAT(k, v) do { if (threadIdx.x == 0) dstat[k] += (unsigned long long)(v); } while (0)
+#else
+#define LSTAT(k, v) do { } while (0)
+#endif
+
+    // ---- phase A of subframe ta over this wavefront's groups (prach_cluster.hip compact_phase_a).  SPEC: ahead of the resolver
+    // of subframe ta - 1 (its grants are not known: a new caller waits for phase B; a matched UE that gets one is taken out again
+    // by the granting thread).  pcA: byte offset of subframe ta's parity block.
+    auto phase_a = [&](const bool SPEC, const int ta, const int prevA, const int acA, const int pcA) __attribute__((always_inline)) {
+        int *const hist = LI(lo::PAR + pcA + lo::P_HIST), *const mloc = LI(lo::PAR + pcA + lo::P_MLOC), *const mlocs = LI(lo::PAR + pcA + lo::P_MLOCS);
+        const int ngroups = (acA + 63) >> 6;
+        for (int m = 0;; m++) {
+            const int j = w + NW * m, g = b + G * j;
+            if (g >= ngroups) break;
+            if ((deadmask >> m) & 1ull) continue;
+            const int sl = j * 64 + lane, i = g * 64 + lane;
+            const int4 r = lrec[sl];
+            const unsigned pk = (unsigned)r.w;
+            const unsigned pg = pk >> PK_PEND_SHIFT; // deferred outcome | grant bit << 3
+            const bool act2 = (pk & 2u) != 0u;        // ACT_M1 or ACT_M3
+            const bool isM1 = (pk & 3u) == (unsigned)ACT_M1;
+            const bool haspre = (pk & (0xffu << PK_PRE_SHIFT)) != 0u;
+            const bool contend = isM1 && haspre && r.z <= ta; // nowBackoff <= 0: stored as expiry subframe when positive
+            const bool trig = r.x == ta;
+            bool lightc = l_light(pk, r.x, r.z, ta, K.rarlim);
+            if (SPEC && pg == (unsigned)PEND_CALLER) lightc = false;
+            bool quiet = pg == 0u && (!act2 || (!contend && !trig && !(isM1 && !haspre)));
+            bool done = (pk & 3u) == (unsigned)ACT_DONE;
+            if (g * 64 + 64 > prevA) { // the (at most two) groups the arrival front is in: per-lane range checks
+                const bool valid = i < acA, old = i < prevA;
+                lightc = lightc && old;
+                quiet = !valid || (old && quiet);
+                done = (valid && done) || i >= nUE;
+            }
+            const bool heavy = !lightc && !quiet;
+            if (!__any(lightc || heavy)) {
+                if (__all(done)) deadmask |= 1ull << m; // nothing will ever happen in this group again
+                continue;
+            }
+            if (lightc) { // Beta.c:245 + the txTime++ of Beta.c:346,358
+                const bool bump = pg != 0u;
+                const bool member = bump || trig; // matched by a preambleCollision scan in this subframe
+                if (pg != (unsigned)PEND_STAY) { // (steady contention is not rewritten: it follows from the record's age)
+                    const unsigned npk = ((pk & 0x0FFFFFFFu) + (1u << PK_RAR_SHIFT)) | (member ? (unsigned)PEND_STAY << PK_PEND_SHIFT : 0u);
+                    lrec[sl] = make_int4(bump ? ta : r.x, r.y, r.z, (int)npk);
+                }
+                if (member) {
+                    const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
+                    atomicAdd(&hist[p1], 1);
+                    int *const ml = pg == (unsigned)PEND_STAY ? mlocs : mloc;
+                    if (__atomic_load_n(&ml[p1], __ATOMIC_RELAXED) > i) atomicMin(&ml[p1], i);
+                }
+            }
+            const unsigned long long hm = __ballot(heavy);
+            if (hm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&scal[S_QN], __popcll(hm));
+                base = __shfl(base, 0);
+                if (heavy) queue[base + __popcll(hm & lanemask_lt(lane))] = sl; // (the queue has room for every owned slot)
+            }
+        }
+    };
+
+    // ---- the calls of one subframe (resolver tables at byte offset fa_, N_ gathered events): scan counts and counters; `now`: also
+    // the last-caller table and the singleton list (needed by the grant selection / by PEND_RJOIN of the very next pass)
+    auto calls = [&](const int fa_, const int N_, const bool now) __attribute__((always_inline)) {
+        const int *const fcallA = LI(lo::FCALL + fa_);
+        int *const lcallA = LI(lo::LCALL + fa_);
+        const int nrj = now ? scal[S_NRJ] : 0; // (a deferred subframe has no Msg3 re-entry)
+        int my_coll = 0, my_txop = 0;
+        for (int k = tid; k < N_ + nP; k += WG_THREADS) {
+            int idx = 0, p = 0, ispre = 0;
+            bool caller = false;
+            if (k < N_) {
+                const int2 e = gev[k];
+                const int type = e.y & 7;
+                if (type == EVL_CALLER || type == EVL_RESETCAND) { caller = true; idx = e.x; p = (e.y >> 4) & 0xff; ispre = (e.y >> 3) & 1; }
+            } else {
+                p = k - N_;
+                if (fcallA[p] != INT_MAX && !LI(lo::FIE + fa_)[p]) { caller = true; idx = fcallA[p]; ispre = 1; } // a STAY pre-member calls first
+            }
+            if (!caller) continue;
+            const bool first = idx == fcallA[p];
+            int rj = 0;
+            if (nrj > 0) { // Msg3-timeout re-entries that stayed matched since the previous call on this bucket (rare)
+                int prev = (!first) ? fcallA[p] : -1;
+                for (int j = 0; j < N_; j++) {
+                    const int2 ej = gev[j];
+                    const int tj = ej.y & 7;
+                    if ((tj == EVL_CALLER || tj == EVL_RESETCAND) && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) prev = ej.x;
+                }
+                for (int j = 0; j < N_; j++) {
+                    const int2 ej = gev[j];
+                    if ((ej.y & 7) == EVL_RJOIN && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) rj++;
+                }
+            }
+            const int check = 1 + (first ? LI(lo::TOTAL + fa_)[p] - ispre - LI(lo::NLV + fa_)[p] : 0) + rj;
+            if (now && lcallA[p] < idx) atomicMax(&lcallA[p], idx);
+            if (check == 1) {
+                if (now) {
+                    const int s_ = atomicAdd(&scal[S_NS], 1);
+                    if (s_ < LSC) LI(lo::SIDX)[s_] = idx;
+                }
+                my_txop += 1;
+            } else if (withnoma) { // WithNOMA:650-652
+                my_coll += check; my_txop += check;
+            } else { // Beta.c:349-351
+                my_coll += 1; my_txop += 1;
+            }
+        }
+        if (__any((my_coll | my_txop) != 0)) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { my_coll += __shfl_down(my_coll, d); my_txop += __shfl_down(my_txop, d); }
+            if (lane == 0) { if (my_coll) atomicAdd(&scal[S_COLL], my_coll); if (my_txop) atomicAdd(&scal[S_TXOP], my_txop); }
+        }
+    };
+    int pendN = -1, pendFa = 0; // deferred calls of the previous subframe (pendN < 0: none)
+
+    for (int t = 0; t < stop && status == PRACH_OK; t++) {
+        steps++;
+        tlast = t;
+        if (t5 == 0) grantCheck = 0; // Beta.c:112 (hard-coded 5)
+        const int prevAC = activeCheck;
+        if (tA == 0 && activeCheck != nUE) { // Beta.c:121-134: this access slot's arrivals (fetched a slot ago)
+            activeCheck = acNext;
+            acNext = sched[slotA + 1]; // (the table has maxTime / accessTime + 2 entries)
+        }
+        const int parity = t & 1;
+        const unsigned tag = (unsigned)(t + 1);
+        const int pc = parity * lo::PARSZ, pn = (parity ^ 1) * lo::PARSZ; // parity blocks of this subframe / of the next one
+        const int fa = parity * lo::RBSZ, fb = (parity ^ 1) * lo::RBSZ;   // resolver tables: this subframe's resolver fills [A]; the pass reads [B]
+        PRACH_G long long *const mbpar = mbox + (size_t)parity * parstride;
+        PRACH_G long long *const mygr = mbpar + myoff;
+        PRACH_G long long *const mbev = mygr + 1 + nP;
+        int *const fcallA = LI(lo::FCALL + fa);
+        LSTAMP(0); // loop head
+
+        if (t == 0) { // (every later subframe's phase A has run ahead, inside the exchange of the subframe before)
+            phase_a(false, 0, prevAC, activeCheck, pc);
+            __syncthreads();
+        }
+        { // ---- phase B: the queued UEs through the full body, 64 at a time ----
+            int c_succ = 0, c_contf = 0;
+            const int qn = scal[S_QN];
+            LSTAT(0, qn);
+            for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
+                const bool v = q0 + lane < qn;
+                const int sl = v ? queue[q0 + lane] : 0;
+                const int i = l_idx_of(K, sl);
+                int4 r = make_int4(-1, 0, 0, 0);
+                unsigned ndc = 0;
+                if (v) { r = lrec[sl]; ndc = lnd[sl]; }
+                // (an idle lane keeps the idle record: l_step leaves it alone)
+                l_step(smem, K, lrec, lnd, ldraw, pc, fb, t, prevAC, mbev, tag, lane, i, sl, v && i < activeCheck, r, ndc, c_succ, c_contf);
+            }
+            if (__any((c_succ | c_contf) != 0)) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+                if (lane == 0) {
+                    if (c_succ) atomicAdd(&scal[S_NSUCC], c_succ);
+                    if (c_contf) atomicAdd(&scal[S_CONTF], c_contf);
+                }
+            }
+        }
+        LSTAMP(1); // phase B
+        __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
+        LSTAMP(2);
+
+        // early leavers below this workgroup's lowest caller are the only ones a rank can need
+        {
+            const int ncand = scal[S_NCAND];
+            const int *const mloc = LI(lo::PAR + pc + lo::P_MLOC), *const mlocs = LI(lo::PAR + pc + lo::P_MLOCS);
+            for (int k = tid; k < ncand; k += WG_THREADS) {
+                const int2 c = LI2(lo::LCAND)[k];
+                if (c.x < min(mloc[c.y], mlocs[c.y])) {
+                    const int es = atomicAdd(&scal[S_NEV], 1);
+                    if (es < CLUSTER_EVW) lst(mbev + es, lmk((unsigned)c.x, (unsigned)(EVL_LEAVER | (c.y << 4)), tag));
+                }
+            }
+            if (tid == 64) { scal[S_NS] = 0; scal[S_NRC] = 0; scal[S_NRJ] = 0; scal[S_QN] = 0; } // (the queue has been consumed)
+        }
+        LSTAMP(3); // leaver filter
+        __syncthreads(); // S2
+        LSTAMP(4);
+        // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
+        if (tid < nP) {
+            const int ml = min(LI(lo::PAR + pc + lo::P_MLOC)[tid], LI(lo::PAR + pc + lo::P_MLOCS)[tid]);
+            lst(mygr + 1 + tid, lmk((unsigned)LI(lo::PAR + pc + lo::P_HIST)[tid], ml == INT_MAX ? GRL_NONE : (unsigned)ml, tag));
+        } else if (tid == 64) {
+            const int nevraw = scal[S_NEV];
+            lst(mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
+            scal[S_NEV] = 0; scal[S_NCAND] = 0;
+        }
+        LSTAMP(5); // publish
+        // round 1: the bucket granules of every workgroup and, on the last wavefront, the headers.  The loads are issued, phase A of
+        // the NEXT subframe runs while they (and the other workgroups' stores) are in flight, then every granule is checked and, if
+        // its tag is still the old one, re-read until it arrives.
+        const bool ahead = t + 1 < stop;
+        long long gv[3] = {0, 0, 0}, hv = 0;
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            if (r1p[u] >= 0) gv[u] = lld(mbpar + r1off[u]);
+        if (hl >= 0 && hl < G) hv = lld(mbpar + hoff);
+        long long ev2[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (r2wg[u] >= 0) ev2[u] = lld(mbpar + r2off[u]);
+        if (ahead) {
+            // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the pass of
+            // subframe t left them
+            const int acN = (tA + 1 == aT && activeCheck != nUE) ? acNext : activeCheck;
+            phase_a(true, t + 1, activeCheck, acN, pn);
+        }
+        { // refill: the next two draws of every UE that drew in this subframe's phase B (off the chain: the exchange is in flight)
+            const int nrq = min(scal[S_NRQ], LRQ);
+            LSTAT(3, scal[S_NRQ]);
+            for (int k = tid; k < nrq; k += WG_THREADS) {
+                const int sl = LI(lo::RQ)[k];
+                const int i = l_idx_of(K, sl);
+                const unsigned nd = lnd[sl] & ~ND_READY;
+                ldraw[sl] = make_int2(philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd, (unsigned)nUE, (unsigned)K.variant),
+                                      philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd + 1u, (unsigned)nUE, (unsigned)K.variant));
+                lnd[sl] = nd | ND_READY;
+            }
+        }
+        if (pendN >= 0) { calls(pendFa, pendN, false); pendN = -1; } // the previous subframe's deferred calls (its event list is intact until S3)
+        LSTAMP(6); // phase A ahead
+        {
+            int *const total = LI(lo::TOTAL + fa);
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                if (r1p[u] >= 0) {
+                    long long g_ = gv[u];
+                    if (!lok(g_, tag)) { LSTAT(1, 1); g_ = lwait(mbpar + r1off[u], tag, smem); }
+                    const unsigned h = (unsigned)g_ & 0xFFFFFu, ml = (unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu;
+                    if (h) atomicAdd(&total[r1p[u]], (int)h);
+                    if (ml != GRL_NONE) atomicMin(&fcallA[r1p[u]], (int)ml);
+                }
+            }
+            for (int k = tid + 3 * WG_THREADS; k < G * nP; k += WG_THREADS) { // (more than 3072 bucket granules)
+                const int wg = k / nP, p = k - wg * nP;
+                const long long g_ = lwait(mbpar + (unsigned)wg * mbs + 1u + (unsigned)p, tag, smem);
+                const unsigned h = (unsigned)g_ & 0xFFFFFu, ml = (unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu;
+                if (h) atomicAdd(&total[p], (int)h);
+                if (ml != GRL_NONE) atomicMin(&fcallA[p], (int)ml);
+            }
+            if (hl >= 0) {
+                int nev = 0, nsuc = 0, ovf = 0;
+                if (hl < G) {
+                    long long g_ = hv;
+                    if (!lok(g_, tag)) g_ = lwait(mbpar + hoff, tag, smem);
+                    const unsigned w0 = (unsigned)g_ & 0xFFFFFu;
+                    nev = (int)(w0 & 0x1FFFu); ovf = (int)((w0 >> 13) & 1u); nsuc = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu);
+                }
+                int x = nev;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (hl >= d) x += y; }
+                LI(lo::EVOFF)[hl] = x - nev;
+                int rem = max(nev - LEPF, 0); // events beyond the granules fetched in round 1
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) { nsuc += __shfl_down(nsuc, d); ovf |= __shfl_down(ovf, d); rem += __shfl_down(rem, d); }
+                if (hl == 63) { scal[S_NTOT] = x; LI(lo::EVOFF)[64] = x; }
+                if (hl == 0) scal[S_NREM] = rem;
+                if (hl == 0) { scal[S_NSUCCTOT] = nsuc; scal[S_OVF] = ovf; }
+            }
+        }
+        LSTAMP(7); // round-1 granules taken
+        __syncthreads(); // S3: totals, lowest definite callers, event offsets (and the next subframe's phase A)
+        LSTAMP(8);
+        if (tid < NPCL) { // this parity is used again in two subframes
+            LI(lo::PAR + pc + lo::P_HIST)[tid] = 0; LI(lo::PAR + pc + lo::P_MLOC)[tid] = INT_MAX;
+            LI(lo::PAR + pc + lo::P_MLOCS)[tid] = INT_MAX; LI(lo::PAR + pc + lo::P_CANDN)[tid] = 0;
+            // the resolver tables of the subframe before (read by this subframe's pass and by its deferred calls, both done): next subframe's [A]
+            LI(lo::FCALL + fb)[tid] = INT_MAX; LI(lo::LCALL + fb)[tid] = -1; LI(lo::TOTAL + fb)[tid] = 0; LI(lo::NLV + fb)[tid] = 0; LI(lo::FIE + fb)[tid] = 0;
+        }
+        if (tid == 64) scal[S_NRQ] = 0; // (the refill list has been consumed)
+        if (scal[S_STATUS] != PRACH_OK) { status = scal[S_STATUS]; time_exit = t; break; }
+        const int N = scal[S_NTOT];
+        if (scal[S_OVF] || N > LEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on the general kernels
+        // the event granules: the first LEPF of every mailbox came with round 1 (each by the thread that fetched it), classified
+        // against the lowest definite callers; a mailbox with more has the rest read now (a second round trip, rare)
+        {
+            const int *const evoff = LI(lo::EVOFF);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (r2wg[u] >= 0) {
+                    const int o0 = evoff[r2wg[u]], nev = evoff[r2wg[u] + 1] - o0;
+                    if (r2es[u] < nev) {
+                        long long e = ev2[u];
+                        if (!lok(e, tag)) { LSTAT(2, 1); e = lwait(mbpar + r2off[u], tag, smem); }
+                        const int2 ev = make_int2((int)((unsigned)e & 0xFFFFFu), (int)((unsigned)((unsigned long long)e >> 32) & 0xFFFFFu));
+                        gev[o0 + r2es[u]] = ev;
+                        l_classify(smem, fa, o0 + r2es[u], ev);
+                    }
+                }
+            }
+            if (scal[S_NREM] > 0) {
+                for (int k = tid; k < N; k += WG_THREADS) {
+                    int lo_ = 0, hi_ = G; // workgroup whose segment holds event k
+                    while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (evoff[mid] <= k) lo_ = mid; else hi_ = mid; }
+                    const int es = k - evoff[lo_];
+                    if (es < LEPF) continue;
+                    const long long e = lwait(mbpar + (unsigned)lo_ * mbs + 1u + (unsigned)nP + (unsigned)es, tag, smem);
+                    const int2 ev = make_int2((int)((unsigned)e & 0xFFFFFu), (int)((unsigned)((unsigned long long)e >> 32) & 0xFFFFFu));
+                    gev[k] = ev;
+                    l_classify(smem, fa, k, ev);
+                }
+            }
+        }
+        LSTAMP(9); // round 2
+        if (N > 0) __syncthreads(); // S4: events gathered and classified against the lowest DEFINITE callers (N is uniform)
+        LSTAMP(10);
+
+        // ---- resolve (identical on every workgroup of the cluster) ----
+        const int nrc = scal[S_NRC];
+        if (nrc > 0) { // rare: reset cycles that may re-join — decided strictly in index order, then recount
+            if (nrc > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (tid < 64) l_resolve_reset_candidates(smem, fa, nrc, nP);
+            else if (tid < 64 + NPCL) { LI(lo::NLV + fa)[tid - 64] = 0; LI(lo::FIE + fa)[tid - 64] = 0; }
+            __syncthreads();
+            for (int k = tid; k < N; k += WG_THREADS) {
+                const int2 e = gev[k];
+                const int type = e.y & 7, p = (e.y >> 4) & 0xff;
+                if (type == EVL_LEAVER) { if (e.x < fcallA[p]) atomicAdd(&LI(lo::NLV + fa)[p], 1); }
+                else if ((type == EVL_CALLER || type == EVL_RESETCAND) && e.x == fcallA[p]) LI(lo::FIE + fa)[p] = 1;
+            }
+            __syncthreads();
+        }
+        // every call: scan count `check` (Beta.c:321-330), counters (Beta.c:334,349-351 / WithNOMA:650-652).  With no UL grant left in
+        // this 5 ms window and no Msg3 re-entry in this subframe nothing the calls produce is needed by the next pass — the
+        // singleton list only feeds the grant selection, the last-caller table only PEND_RJOIN — so they are DEFERRED into the
+        // next subframe's exchange window (off the critical chain; the counters are the same whenever they are added up).
+        const int Gr = max(0, nGrantUL - 1 - grantCheck); // Beta.c:336-347
+        const bool defer = Gr == 0 && nrc == 0 && scal[S_NRJ] == 0 && t + 1 < stop;
+        if (defer) { pendN = N; pendFa = fa; }
+        else calls(fa, N, true);
+        LSTAMP(11); // calls
+        if (!defer) __syncthreads(); // S5: calls done; singles listed
+        LSTAMP(12);
+        const int ns = defer ? 0 : scal[S_NS]; // (deferred: the window's grants are used up, grantCheck no longer matters: Beta.c:336)
+        if (ns > LSC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+        // An UL grant: the grant bit into the UE's record.  Phase A of subframe t+1 has already run: it took a matched UE
+        // (PEND_STAY) for steadily contending, counted it into its bucket and did not queue it — take it out again and queue it.
+        // A granted UE was the only caller of a bucket nobody else stayed matched in, so it is the only one phase A counted there
+        // as matched before (MLOCS).
+        auto grant = [&](const int my) {
+            const unsigned x = (unsigned)((my >> 6) - b);
+            const unsigned q = x / (unsigned)G; // (owner check done by the caller: x is a multiple of G)
+            const int sl = (int)(q * 64u) + (my & 63);
+            atomicOr(reinterpret_cast<unsigned *>(&lrec[sl].w), PK_GRANT_BIT);
+            if (ahead) {
+                const int4 r = lrec[sl];
+                const unsigned pk = (unsigned)r.w & ~PK_GRANT_BIT;
+                if ((pk >> PK_PEND_SHIFT) == (unsigned)PEND_STAY && l_light(pk, r.x, r.z, t + 1, K.rarlim)) {
+                    const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
+                    atomicSub(&LI(lo::PAR + pn + lo::P_HIST)[p1], 1);
+                    LI(lo::PAR + pn + lo::P_MLOCS)[p1] = INT_MAX;
+                    queue[atomicAdd(&scal[S_QN], 1)] = sl; // ... and its grant is applied by phase B of subframe t+1
+                }
+            }
+        };
+        auto mine = [&](const int my) { return ((unsigned)(my >> 6) % (unsigned)G) == (unsigned)b; };
+        if (Gr > 0 && ns > 0 && ns <= 64) {
+            // up to one wavefront of singleton callers: every lane ranks its own index against the others through v_readlane
+            if (tid < 64) {
+                const int nsu = __builtin_amdgcn_readfirstlane(ns);
+                const int my = tid < nsu ? LI(lo::SIDX)[tid] : INT_MAX;
+                int rank = 0;
+                for (int s_ = 0; s_ < nsu; s_++) rank += __builtin_amdgcn_readlane(my, s_) < my ? 1 : 0;
+                if (tid < nsu && rank < Gr && mine(my)) grant(my);
+            }
+        } else if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
+            // the Gr lowest-index singleton callers, in O(ns): counts per index bin, block-wide exclusive prefix, whole bins below the
+            // crossing bin are granted, the crossing bin is ranked exactly
+            int *const bins = LI(lo::BINS), *const sidx = LI(lo::SIDX), *const rcl = LI(lo::RCL), *const wtot = LI(lo::WTOT);
+            bins[tid] = 0;
+            if (tid == 0) scal[S_NCROSS] = 0;
+            __syncthreads();
+            for (int j = tid; j < ns; j += WG_THREADS) atomicAdd(&bins[sidx[j] >> binshift], 1);
+            __syncthreads();
+            {
+                const int c = bins[tid];
+                int x = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+                if (lane == 63) wtot[w] = x;
+                __syncthreads();
+                int add = 0;
+                for (int k = 0; k < w; k++) add += wtot[k];
+                bins[tid] = x - c + add; // exclusive prefix
+            }
+            __syncthreads();
+            for (int j = tid; j < ns; j += WG_THREADS) {
+                const int my = sidx[j];
+                const int bin = my >> binshift;
+                const int before = bins[bin];
+                if (before >= Gr) continue;
+                const int cnt = (bin + 1 < LGB ? bins[bin + 1] : ns) - before;
+                if (before + cnt <= Gr) { if (mine(my)) grant(my); }
+                else { const int s_ = atomicAdd(&scal[S_NCROSS], 1); if (s_ < RCCAP) rcl[s_] = my; }
+            }
+            __syncthreads();
+            const int ncross = scal[S_NCROSS];
+            if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (tid < ncross) {
+                const int my = rcl[tid];
+                int rank = bins[my >> binshift];
+                for (int m = 0; m < ncross; m++) rank += rcl[m] < my ? 1 : 0;
+                if (rank < Gr && mine(my)) grant(my);
+            }
+        }
+        grantCheck += ns;
+        const int nsucc_tot = scal[S_NSUCCTOT];
+        LSTAMP(13); // grants
+        if (Gr > 0 && ns > 0) __syncthreads(); // S6: the grants are in the records before the next pass reads them
+        LSTAMP(14);
+        if (scal[S_STATUS] != PRACH_OK) { status = scal[S_STATUS]; time_exit = t; break; }
+        if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
+        if (++t5 == 5) t5 = 0;
+        if (++tA == aT) { tA = 0; slotA++; }
+    }
+    __syncthreads();
+    if (pendN >= 0 && status == PRACH_OK) { calls(pendFa, pendN, false); pendN = -1; }
+    __syncthreads();
+
+    // ---- the deferred outcome of the last subframe (prach_cluster.hip cluster_pass<3>), end-of-trial sums (Beta.c:185-197)
+    // and the logged fields (Beta.c:501-508) of the owned UEs
+    const int tend = tlast + 1;
+    {
+        const int fl = (tlast & 1) * lo::RBSZ;
+        const int *const fcall = LI(lo::FCALL + fl), *const lcall = LI(lo::LCALL + fl);
+        PRACH_G int *const timers = (PRACH_G int *)PD->timers;
+        PRACH_G v4i_t *const logs = (PRACH_G v4i_t *)PD->logs;
+        long long sumT = 0;
+        int ptcS = 0, fcS = 0;
+        unsigned long long ndS = 0;
+        for (int x = tid; x < lgroups * 64 && x < lslots; x += WG_THREADS) {
+            const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
+            if (g >= totgroups || i >= nUE) continue;
+            const int4 r = lrec[x];
+            UeState u = unpack(r);
+            if (status == PRACH_OK && tlast >= 0 && u.pend != PEND_NONE) { // (as in l_step, with tp = tlast)
+                const int tp = tlast;
+                if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; }
+                if ((unsigned)r.w & PK_GRANT_BIT) {
+                    u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
+                    if (u.pend == PEND_RESET) u.bo = 0;
+                } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
+                    u.tx = tp + 1;
+                } else if (u.pend == PEND_RESET) {
+                    const int q = u.bo, tmp = u.tx;
+                    const int bumped = fcall[q] < i ? 1 : 0;
+                    const int xx = slot_align_fm(tp + bumped + tmp, K.fmA);
+                    if (xx == tp) { u.bo = 0; u.tx = tp + 1; }
+                    else { u.tx = xx; u.bo = xx; }
+                } else if (u.pend == PEND_PASSIVE) {
+                    if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
+                } else {
+                    if (lcall[u.pre - 1] > i) u.tx = tp + 1;
+                }
+                u.pend = PEND_NONE;
+            }
+            const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
+            const int ptc = K.ptc[i], fc = K.fcnt[i];
+            if (u.act == ACT_DONE) { sumT += timer; ptcS += ptc; fcS += fc; }
+            if (u.act != ACT_IDLE) ndS += lnd[x] & ~ND_READY; // (a UE that never arrived drew nothing)
+            timers[i] = u.act == ACT_DONE ? timer : INT_MIN;
+            if (logs) {
+                prach_ue_log o;
+                o.idx = i; o.timer = timer; o.active = u.act - 1; o.txTime = u.tx; o.firstTxTime = K.ftt[i];
+                o.secondTxTime = K.stt[i]; o.nowBackoff = now_backoff(u.bo, tend); o.preamble = u.pre - 1;
+                o.preambleChange = u.pre != 0; o.rarWindow = u.rar; o.maxRarCounter = u.mrc; o.preambleTxCounter = ptc;
+                o.msg2Flag = (u.act == ACT_M3 || u.act == ACT_DONE); o.connectionRequest = u.conn == 2 ? 48 : u.conn;
+                o.msg4Flag = u.act == ACT_DONE; o.failCount = fc;
+                store_log(logs, i, o);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            sumT += __shfl_down(sumT, d); ptcS += __shfl_down(ptcS, d); fcS += __shfl_down(fcS, d); ndS += __shfl_down(ndS, d);
+        }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&scal[S_SUMT]), (unsigned long long)sumT);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&scal[S_ND]), ndS);
+            atomicAdd(&scal[S_PTC], ptcS);
+            atomicAdd(&scal[S_FC], fcS);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { // DevResult was zeroed by the engine before the launch
+        PRACH_G DevResult *o = (PRACH_G DevResult *)PD->out;
+        gadd(&o->sumTimer, *reinterpret_cast<long long *>(&scal[S_SUMT]));
+        gadd(&o->draws, *reinterpret_cast<unsigned long long *>(&scal[S_ND]));
+        gadd(&o->ptcSum, scal[S_PTC]);
+        gadd(&o->fcSum, scal[S_FC]);
+        gadd(&o->nSuccess, scal[S_NSUCC]);
+        gadd(&o->finalSuccess, scal[S_NSUCC]);
+        gadd(&o->continueFailed, scal[S_CONTF]);
+        if (status != PRACH_OK) gmin(&o->status, status);
+        if (b == 0) {
+#ifdef PRACH_STAMPS
+            for (int k = 0; k < 16; k++) o->fstamps[k] = fstamps[k];
+            for (int k = 0; k < 4; k++) o->dbg[k] = dstat[k];
+#endif
+            o->time_exit = time_exit;
+            o->collisionPreambles = scal[S_COLL];
+            o->totalPreambleTxop = scal[S_TXOP];
+            o->activeCheck = activeCheck;
+            o->steps = steps;
+        }
+    }
+}
+
+size_t lcluster_kernel_lds_bytes(int lslots) { return (size_t)lo::TAIL + (size_t)lslots * 28; }
+int lcluster_max_preambles() { return NPCL; }
+
+hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, hipStream_t stream) {
+    const size_t lds = lcluster_kernel_lds_bytes(lslots);
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL(lcluster_kernel, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, lslots);
+    return hipGetLastError();
+}
+
+int lcluster_kernel_blocks_per_cu(int lslots) {
+    const size_t lds = lcluster_kernel_lds_bytes(lslots);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&lcluster_kernel), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;
+    return nb;
+}
+
+} // namespace prach
