@@ -13,7 +13,11 @@
  *
  * Extensions (not in the reference): --program beta|withnoma|noma, --rng glibc|philox, --nue N,
  * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N, --csv FILE (--program beta: the results.csv of
- * AveragePerformance.py over the --times seeds of every sweep point, written by prach_results_csv_*).
+ * AveragePerformance.py over the --times seeds of every sweep point, written by prach_results_csv_*),
+ * --gpus N: the --times x sweep grid sharded over N devices of the node by host C — one forked child per device,
+ * forked BEFORE any HIP call, trials dealt by descending cost (Philox: any trial anywhere; glibc: whole seeds, because
+ * the sweep of a seed is chained through its rand() stream), results merged by the parent through shared memory; the
+ * reference runs the grid serially (RandomAccessWithNOMA.c:216-221).
  */
 #define _GNU_SOURCE
 #include "../../include/prach.h"
@@ -21,8 +25,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <time.h>
+#include <unistd.h>
 
 static void usage_and_exit(void) { /* text of WithNOMA:160-202 */
     printf("--times         -t : Simulation times (int)\n");
@@ -66,8 +73,86 @@ static int is(const char *a, const char *l, const char *s1, const char *s2) {
 }
 static void die(const char *msg) { printf("%s", msg); exit(-1); }
 
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* One worker = one device: runs the trials idx[0..m) of the grid on `device` and leaves every prach_result in the (shared)
+ * array `res`; per-trial files are written by the worker itself (independent files).  Philox trials go out in calls of up to
+ * 1024 trials (one workgroup or cluster per trial); in glibc mode `idx` holds whole seeds in grid order and the sweep of a
+ * seed is chained through cfg.stream_offset like the reference's single srand() per seed (WithNOMA:219-221): one call per
+ * sweep point with all the worker's seeds in it.  Returns 0 or an exit code. */
+static int run_worker(int device, const prach_cfg *cfgs, const int *idx, int m, prach_result *res, double *lat_out, int want_logs,
+                      const char *outdir, int glibc, int npts) {
+    prach_engine *eng = NULL;
+    int rc = prach_engine_create(device, &eng);
+    if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: device %d: %s\n", device, prach_strerror(rc)); return 2; }
+    const double t0 = now_s();
+    const int CH = glibc ? m : 1024;
+    prach_cfg *c = (prach_cfg *)malloc(sizeof(prach_cfg) * (size_t)(m > 0 ? m : 1));
+    prach_result *r = (prach_result *)malloc(sizeof(prach_result) * (size_t)(m > 0 ? m : 1));
+    prach_ue_log **logs = want_logs ? (prach_ue_log **)calloc((size_t)(m > 0 ? m : 1), sizeof(prach_ue_log *)) : NULL;
+    if (!c || !r || (want_logs && !logs)) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+    if (!glibc) {
+        for (int a = 0; a < m; a += CH) {
+            const int n = m - a < CH ? m - a : CH;
+            for (int k = 0; k < n; k++) {
+                c[k] = cfgs[idx[a + k]];
+                if (want_logs) {
+                    logs[k] = (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)c[k].nUE);
+                    if (!logs[k]) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+                }
+            }
+            rc = prach_run_trials(eng, c, n, r, logs);
+            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+            const double lat = now_s() - t0;
+            for (int k = 0; k < n; k++) {
+                res[idx[a + k]] = r[k];
+                lat_out[idx[a + k]] = lat;
+                if (cfgs[idx[a + k]].variant != PRACH_VARIANT_NOMA_C) {
+                    rc = prach_write_trial_files(&c[k], &r[k], want_logs ? logs[k] : NULL, lat, outdir);
+                    if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+                }
+                if (want_logs) { free(logs[k]); logs[k] = NULL; }
+            }
+        }
+    } else { /* idx = seeds' trials in grid order: idx[s * npts + k]; chained per seed */
+        const int nseeds = m / npts;
+        uint64_t *offset = (uint64_t *)calloc((size_t)(nseeds > 0 ? nseeds : 1), sizeof(uint64_t));
+        if (!offset) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+        for (int k = 0; k < npts; k++) {
+            for (int s_ = 0; s_ < nseeds; s_++) {
+                c[s_] = cfgs[idx[s_ * npts + k]];
+                c[s_].stream_offset = offset[s_];
+                if (want_logs) {
+                    logs[s_] = (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)c[s_].nUE);
+                    if (!logs[s_]) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+                }
+            }
+            rc = prach_run_trials(eng, c, nseeds, r, logs);
+            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+            const double lat = now_s() - t0;
+            for (int s_ = 0; s_ < nseeds; s_++) {
+                offset[s_] += r[s_].draws;
+                res[idx[s_ * npts + k]] = r[s_];
+                lat_out[idx[s_ * npts + k]] = lat;
+                rc = prach_write_trial_files(&c[s_], &r[s_], want_logs ? logs[s_] : NULL, lat, outdir);
+                if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+                if (want_logs) { free(logs[s_]); logs[s_] = NULL; }
+            }
+        }
+        free(offset);
+    }
+    free(c); free(r); free(logs);
+    prach_engine_destroy(eng);
+    return 0;
+}
+
 int main(int argc, char *argv[]) {
-    int randomMax = 1, variant = PRACH_VARIANT_WITHNOMA_C, rng = PRACH_RNG_GLIBC, device = 0, want_logs = 1;
+    int randomMax = 1, variant = PRACH_VARIANT_WITHNOMA_C, rng = PRACH_RNG_GLIBC, device = 0, want_logs = 1, gpus = 1;
     int sweep_lo = 10000, sweep_hi = 100000, sweep_step = 10000; /* WithNOMA:221 */
     const char *outdir = ".", *csv_path = NULL;
     /* --program must be known before the defaults are laid down */
@@ -131,6 +216,9 @@ int main(int argc, char *argv[]) {
             want_logs = atoi(v) != 0;
         } else if (strcmp(a, "--device") == 0) {
             device = atoi(v);
+        } else if (strcmp(a, "--gpus") == 0) {
+            if (atoi(v) < 1 || atoi(v) > 64) die("--gpus N: 1..64 devices of this node");
+            gpus = atoi(v);
         } else if (strcmp(a, "--csv") == 0) {
             csv_path = v;
         } else {
@@ -139,24 +227,94 @@ int main(int argc, char *argv[]) {
     }
     base.rng_mode = rng;
     if (csv_path && variant != PRACH_VARIANT_BETA_C) die("--csv needs --program beta (AveragePerformance.py reads its six-number Results.txt)");
+    if (variant == PRACH_VARIANT_NOMA_C) { base.rng_mode = rng = PRACH_RNG_PHILOX; want_logs = 0; }
 
-    if (variant == PRACH_VARIANT_NOMA_C) { /* NOMA.c main: no banner, one line per trial, "Done" per seed */
-        prach_engine *eng = NULL;
-        int rc = prach_engine_create(device, &eng);
-        if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-        char line[256], path[1024];
+    /* the grid: trial (seed s, sweep point k) = cfgs[s * npts + k], the reference's loop order (WithNOMA:216-221 / NOMA.c:644-647) */
+    const int npts = (sweep_hi - sweep_lo) / sweep_step + 1;
+    const int ntr = randomMax * npts;
+    const int glibc = rng == PRACH_RNG_GLIBC;
+    prach_cfg *cfgs = (prach_cfg *)malloc(sizeof(prach_cfg) * (size_t)ntr);
+    /* results and per-trial latencies live in shared memory: the workers (children) fill them, the parent prints and merges */
+    prach_result *res = (prach_result *)mmap(NULL, sizeof(prach_result) * (size_t)ntr, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    double *lat = (double *)mmap(NULL, sizeof(double) * (size_t)ntr, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (!cfgs || res == MAP_FAILED || lat == MAP_FAILED) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+    for (int s_ = 0; s_ < randomMax; s_++)
+        for (int k = 0; k < npts; k++) {
+            prach_cfg *c = &cfgs[s_ * npts + k];
+            *c = base;
+            c->nUE = sweep_lo + k * sweep_step;
+            c->seed = (uint64_t)s_;
+        }
+    if (variant == PRACH_VARIANT_NOMA_C) {
+        char path[1024];
         snprintf(path, sizeof path, "%s/TestResults", outdir);
         mkdir(path, 0755);
-        for (int seed = 0; seed < randomMax; seed++) {
-            for (int n = sweep_lo; n <= sweep_hi; n += sweep_step) {
-                prach_cfg c = base;
-                c.nUE = n; c.seed = (uint64_t)seed; c.rng_mode = PRACH_RNG_PHILOX;
-                prach_result r;
-                rc = prach_run_trials(eng, &c, 1, &r, NULL);
-                if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-                prach_format_noma_line(&c, &r, line, sizeof line);
+    } else {
+        if (base.uniform) printf("Traffic model: Uniform\n\n"); /* WithNOMA:208-213 */
+        else printf("Traffic model: Beta\n\n");
+        fflush(stdout);
+    }
+
+    /* deal the trials to the workers: longest first onto the least loaded (cost = nUE x subframes); glibc mode deals whole seeds */
+    if (gpus > ntr) gpus = ntr;
+    if (glibc && gpus > randomMax) gpus = randomMax;
+    int **widx = (int **)calloc((size_t)gpus, sizeof(int *));
+    int *wn = (int *)calloc((size_t)gpus, sizeof(int));
+    double *wload = (double *)calloc((size_t)gpus, sizeof(double));
+    if (!widx || !wn || !wload) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+    for (int w = 0; w < gpus; w++) {
+        widx[w] = (int *)malloc(sizeof(int) * (size_t)ntr);
+        if (!widx[w]) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+    }
+    if (glibc) {
+        for (int s_ = 0; s_ < randomMax; s_++) { /* seeds cost the same: round robin keeps every worker's seeds in grid order */
+            const int w = s_ % gpus;
+            for (int k = 0; k < npts; k++) widx[w][wn[w]++] = s_ * npts + k;
+        }
+    } else {
+        for (int k = npts - 1; k >= 0; k--) /* sweep points are ascending in nUE: descending cost */
+            for (int s_ = 0; s_ < randomMax; s_++) {
+                int best = 0;
+                for (int w = 1; w < gpus; w++) if (wload[w] < wload[best]) best = w;
+                widx[best][wn[best]++] = s_ * npts + k;
+                wload[best] += (double)cfgs[s_ * npts + k].nUE * (double)prach_max_time(&cfgs[s_ * npts + k]);
+            }
+    }
+
+    if (gpus == 1) {
+        int rcw = run_worker(device, cfgs, widx[0], wn[0], res, lat, want_logs, outdir, glibc, npts);
+        if (rcw) return rcw;
+    } else {
+        /* one child per device, forked BEFORE this process touches HIP (a forked copy of an initialised runtime is not usable) */
+        pid_t *pid = (pid_t *)calloc((size_t)gpus, sizeof(pid_t));
+        if (!pid) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
+        for (int w = 0; w < gpus; w++) {
+            pid[w] = fork();
+            if (pid[w] < 0) { perror("prach_sim: fork"); return 2; }
+            if (pid[w] == 0) _exit(run_worker(device + w, cfgs, widx[w], wn[w], res, lat, want_logs, outdir, glibc, npts));
+        }
+        int bad = 0;
+        for (int w = 0; w < gpus; w++) {
+            int st = 0;
+            if (waitpid(pid[w], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                fprintf(stderr, "prach_sim: the worker of device %d failed\n", device + w);
+                bad = 1;
+            }
+        }
+        free(pid);
+        if (bad) return 2;
+    }
+
+    /* the parent prints in the reference's order and merges */
+    char text[4096];
+    if (variant == PRACH_VARIANT_NOMA_C) { /* NOMA.c main: no banner, one line per trial, "Done" per seed */
+        char line[256], path[1024];
+        for (int s_ = 0; s_ < randomMax; s_++) {
+            for (int k = 0; k < npts; k++) {
+                const int q = s_ * npts + k;
+                prach_format_noma_line(&cfgs[q], &res[q], line, sizeof line);
                 fputs(line, stdout);
-                snprintf(path, sizeof path, "%s/TestResults/Sector_%d_Result.txt", outdir, n); /* NOMA.c:603-605 */
+                snprintf(path, sizeof path, "%s/TestResults/Sector_%d_Result.txt", outdir, cfgs[q].nUE); /* NOMA.c:603-605 */
                 FILE *fp = fopen(path, "a");
                 if (!fp) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(PRACH_ERR_IO)); return 2; }
                 fputs(line, fp);
@@ -164,114 +322,27 @@ int main(int argc, char *argv[]) {
             }
             printf("Done\n"); /* NOMA.c:716 */
         }
-        prach_engine_destroy(eng);
         return 0;
     }
-
-    if (base.uniform) printf("Traffic model: Uniform\n\n"); /* WithNOMA:208-213 */
-    else printf("Traffic model: Beta\n\n");
-
-    prach_engine *eng = NULL;
-    int rc = prach_engine_create(device, &eng);
-    if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-
-    const int npts = (sweep_hi - sweep_lo) / sweep_step + 1;
-    char text[4096];
-    double (*csv_acc)[6] = csv_path ? (double (*)[6])calloc((size_t)npts, sizeof(double[6])) : NULL; /* AveragePerformance.py:8 */
-    if (csv_path && !csv_acc) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
-    if (rng == PRACH_RNG_PHILOX) {
-        /* Philox trials are independent: the whole --times x sweep grid runs concurrently in ONE call
-         * (one workgroup cluster per trial); output order and files are the reference's. */
-        const int ntr = randomMax * npts;
-        prach_cfg *cfgs = (prach_cfg *)malloc(sizeof(prach_cfg) * (size_t)ntr);
-        prach_result *res = (prach_result *)malloc(sizeof(prach_result) * (size_t)ntr);
-        prach_ue_log **logs = want_logs ? (prach_ue_log **)calloc((size_t)ntr, sizeof(prach_ue_log *)) : NULL;
-        if (!cfgs || !res || (want_logs && !logs)) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
-        for (int s_ = 0; s_ < randomMax; s_++)
-            for (int k = 0; k < npts; k++) {
-                prach_cfg *c = &cfgs[s_ * npts + k];
-                *c = base;
-                c->nUE = sweep_lo + k * sweep_step;
-                c->seed = (uint64_t)s_;
-                if (want_logs) {
-                    logs[s_ * npts + k] = (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)c->nUE);
-                    if (!logs[s_ * npts + k]) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
-                }
-            }
-        struct timespec ts0, ts1;
-        clock_gettime(CLOCK_MONOTONIC, &ts0);
-        rc = prach_run_trials(eng, cfgs, ntr, res, logs);
-        if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-        clock_gettime(CLOCK_MONOTONIC, &ts1);
-        const double lat = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
-        for (int k = 0; k < ntr; k++) {
-            prach_format_stdout(&cfgs[k], &res[k], lat, text, sizeof text);
-            fputs(text, stdout);
-            rc = prach_write_trial_files(&cfgs[k], &res[k], want_logs ? logs[k] : NULL, lat, outdir);
-            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-            if (want_logs) free(logs[k]);
-        }
-        if (csv_acc)
-            for (int k = 0; k < npts; k++)
-                for (int s_ = 0; s_ < randomMax; s_++) { /* seed order inside a point, AveragePerformance.py:10-19 */
-                    prach_format_results(&cfgs[s_ * npts + k], &res[s_ * npts + k], lat, text, sizeof text);
-                    prach_results_csv_accumulate(csv_acc[k], text);
-                }
-        free(cfgs); free(res); free(logs);
-        goto write_csv;
+    for (int q = 0; q < ntr; q++) {
+        prach_format_stdout(&cfgs[q], &res[q], lat[q], text, sizeof text);
+        fputs(text, stdout);
     }
-    /* glibc mode: within one seed the sweep is chained through the rand() stream (one srand() per seed, WithNOMA:219-221),
-     * but different seeds are independent — so the loop nest is turned inside out: for every nUE point, the trials of ALL
-     * seeds run concurrently in one call, each continuing its own seed's stream.  Output is buffered per seed and
-     * printed in the reference's order. */
-    {
-        uint64_t *offset = (uint64_t *)calloc((size_t)randomMax, sizeof(uint64_t));
-        prach_cfg *cfgs = (prach_cfg *)malloc(sizeof(prach_cfg) * (size_t)randomMax);
-        prach_result *res = (prach_result *)malloc(sizeof(prach_result) * (size_t)randomMax);
-        prach_ue_log **logs = want_logs ? (prach_ue_log **)calloc((size_t)randomMax, sizeof(prach_ue_log *)) : NULL;
-        char **outtxt = (char **)calloc((size_t)randomMax, sizeof(char *));
-        size_t *outlen = (size_t *)calloc((size_t)randomMax, sizeof(size_t));
-        if (!offset || !cfgs || !res || !outtxt || !outlen || (want_logs && !logs)) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
-        for (int s_ = 0; s_ < randomMax; s_++) {
-            outtxt[s_] = (char *)malloc((size_t)npts * 1024);
-            if (want_logs) logs[s_] = (prach_ue_log *)malloc(sizeof(prach_ue_log) * (size_t)sweep_hi);
-            if (!outtxt[s_] || (want_logs && !logs[s_])) { fprintf(stderr, "prach_sim: out of memory\n"); return 2; }
-        }
-        struct timespec ts0, ts1;
-        clock_gettime(CLOCK_MONOTONIC, &ts0);
-        for (int k = 0; k < npts; k++) {
-            for (int s_ = 0; s_ < randomMax; s_++) {
-                cfgs[s_] = base;
-                cfgs[s_].nUE = sweep_lo + k * sweep_step;
-                cfgs[s_].seed = (uint64_t)s_;
-                cfgs[s_].stream_offset = offset[s_];
-            }
-            rc = prach_run_trials(eng, cfgs, randomMax, res, logs);
-            if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-            clock_gettime(CLOCK_MONOTONIC, &ts1);
-            const double lat = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
-            for (int s_ = 0; s_ < randomMax; s_++) {
-                offset[s_] += res[s_].draws;
-                outlen[s_] += prach_format_stdout(&cfgs[s_], &res[s_], lat, outtxt[s_] + outlen[s_], 1024);
-                rc = prach_write_trial_files(&cfgs[s_], &res[s_], want_logs ? logs[s_] : NULL, lat, outdir);
-                if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
-                if (csv_acc) { prach_format_results(&cfgs[s_], &res[s_], lat, text, sizeof text); prach_results_csv_accumulate(csv_acc[k], text); }
-            }
-        }
-        for (int s_ = 0; s_ < randomMax; s_++) { fwrite(outtxt[s_], 1, outlen[s_], stdout); free(outtxt[s_]); if (want_logs) free(logs[s_]); }
-        free(offset); free(cfgs); free(res); free(logs); free(outtxt); free(outlen);
-    }
-write_csv:
-    if (csv_acc) { /* one row per sweep point: mean over the seeds, np.around(., 3), csv.writer's float repr and CRLF */
+    if (csv_path) { /* one row per sweep point: mean over the seeds in seed order (AveragePerformance.py:8-24), np.around(., 3), csv.writer's float repr and CRLF */
         FILE *fp = fopen(csv_path, "wb");
         if (!fp) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(PRACH_ERR_IO)); return 2; }
         for (int k = 0; k < npts; k++) {
-            const size_t n = prach_results_csv_row(csv_acc[k], randomMax, text, sizeof text);
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (int s_ = 0; s_ < randomMax; s_++) {
+                prach_format_results(&cfgs[s_ * npts + k], &res[s_ * npts + k], lat[s_ * npts + k], text, sizeof text);
+                prach_results_csv_accumulate(acc, text);
+            }
+            const size_t n = prach_results_csv_row(acc, randomMax, text, sizeof text);
             fwrite(text, 1, n, fp);
         }
         fclose(fp);
-        free(csv_acc);
     }
-    prach_engine_destroy(eng);
+    for (int w = 0; w < gpus; w++) free(widx[w]);
+    free(widx); free(wn); free(wload); free(cfgs);
     return 0;
 }

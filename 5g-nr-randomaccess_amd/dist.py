@@ -48,6 +48,8 @@ def aggregate_rows(cfgs, results, points):
     agg = np.zeros((len(points), len(AGG_FIELDS)), dtype=np.int64)
     pos = {p: k for k, p in enumerate(points)}
     for c, r in zip(cfgs, results):
+        if r.status != 0:
+            raise RuntimeError(f"trial (seed {int(c.seed)}, nUE {int(c.nUE)}) returned status {r.status}: refusing to aggregate it")
         k = pos[int(c.nUE)]
         row = (1, r.nSuccessUE, r.preambleTxCount, r.sumTimer, r.collisionPreambles, r.totalPreambleTxop,
                r.continueFaliedUEs, r.finalSuccessUEs, r.steps, int(c.nUE) * int(r.steps))

@@ -62,7 +62,7 @@ def main(argv=None):
     eng = pkg.Engine(local_rank)
     t0 = time.perf_counter()
     res = []
-    CH = 512  # trials per call: bounds the device arena
+    CH = 1024  # trials per call: bounds the device arena (2.7 GB per 1024 trials of the sweep)
     for a in range(0, len(mine), CH):
         r, _ = eng.run_trials([cfgs[i] for i in mine[a:a + CH]])
         res.extend(r)

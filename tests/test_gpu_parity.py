@@ -453,6 +453,57 @@ def test_sharded_sweep_driver_two_ranks(pkg, ob, tmp_path):
     assert (tmp_path / "results.csv").read_bytes() == pkg.results_csv([texts[n] for n in (3000, 6000, 9000)])
 
 
+def _run_bench_ranks(nranks, backend, extra, port):
+    import json
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "1", "--warmup", "0",
+           "--times", "3", "--backend", backend] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
+
+
+def _check_grid_line(pkg, ob, out, nranks):
+    """bench.py's N>1 line is BASELINE configs[4] (the --times x sweep grid, strong scaling): the aggregates equal the
+    oracle's, trial by trial, and so does results.csv."""
+    import hashlib
+    assert out["n_gpus"] == nranks and out["scaling"] == "strong" and out["config"]["trials_per_step"] == 30
+    assert len(out["per_rank_sim_seconds"]) == nranks and out["imbalance"] >= 0
+    texts = {n: [] for n in range(10000, 100001, 10000)}
+    succ = {n: 0 for n in texts}
+    upd = 0
+    import concurrent.futures as cf
+
+    def one(job):
+        s, n = job
+        ocfg = ob.make_cfg(n, variant=0)
+        ores, _ = ob.run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, s), want_ues=False)
+        return s, n, ob.format_results(ocfg, ores).decode() + "0.000000", ores.nSuccessUE, n * ores.steps
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for s, n, txt, ns, u in ex.map(one, [(s, n) for s in range(3) for n in texts]):
+            texts[n].append((s, txt)); succ[n] += ns; upd += u
+    assert out["config"]["updates_per_step"] == upd
+    assert out["success_ratio"] == {str(n): succ[n] / (3 * n) for n in texts}
+    csv = pkg.results_csv([[t for _, t in sorted(texts[n])] for n in texts])
+    assert out["results_csv_sha256"] == hashlib.sha256(csv).hexdigest()
+
+
+def test_bench_grid_two_ranks_rehearsal(pkg, ob):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run), rehearsed on ONE GPU: both ranks on cuda:0, gloo
+    for the collective (a one-GPU box has no second device for RCCL)."""
+    _check_grid_line(pkg, ob, _run_bench_ranks(2, "gloo", ["--same-device"], 29541), 2)
+
+
+def test_bench_grid_two_ranks_rccl(pkg, ob):
+    """The same over RCCL (backend nccl: all_reduce on device tensors + gather_object), one rank per GPU — needs two devices."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the RCCL path needs two devices (the driver's 8-GPU scaling run exercises it)")
+    _check_grid_line(pkg, ob, _run_bench_ranks(2, "nccl", [], 29542), 2)
+
+
 def test_beyond_reference_sizes(pkg, ob, engine):
     """nUE = 250 000 (2.5x the reference's largest point): still bit-exact vs the oracle, and one workgroup cluster
     per trial still covers it (interleaved ownership scales with nUE, not with a per-CU capacity)."""
