@@ -1,7 +1,7 @@
 """Development probe: the bench's single trial (BASELINE config 2) under engine options. Not a test.
 usage: gpu_single.py "cluster=32,lds_records=1;cluster=16;lds_records=0" [variant] [nUE] [check]"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 m = g.load_package()
@@ -13,7 +13,7 @@ ref = None
 if check:
     from oracle import binding as ob
     ref, _ = ob.run_trial(ob.make_cfg(nUE, variant=variant), ob.Rng(ob.RNG_PHILOX, 0), want_ues=False)
-DEFAULTS = dict(cluster=0, lds_records=1, pipeline=1, dense=0)
+DEFAULTS = dict(cluster=0, lds_records=1, pipeline=1, dense=0, fast=1)
 for spec in sys.argv[1].split(";"):
     opts = dict(DEFAULTS)
     for kv in filter(None, spec.split(",")):
