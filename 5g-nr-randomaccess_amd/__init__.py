@@ -19,13 +19,14 @@ CLI_PATH = os.path.join(HERE, "prach_sim")
 
 VARIANT_BETA_C, VARIANT_WITHNOMA_C, VARIANT_NOMA_C = 0, 1, 2
 RNG_GLIBC, RNG_PHILOX = 0, 1
+FLAG_SECTOR_GRANTS, FLAG_NOMA_NONSECTOR = 1, 2
 OK = 0
 
 
 class PrachCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("variant", "uniform", "nUE", "nPreamble", "backoff", "nGrantUL",
                                          "maxRarWindow", "maxMsg2TxCount", "accessTime", "rng_mode")] + [
-        ("seed", C.c_uint64), ("stream_offset", C.c_uint64), ("max_steps", C.c_int32), ("reserved", C.c_int32),
+        ("seed", C.c_uint64), ("stream_offset", C.c_uint64), ("max_steps", C.c_int32), ("flags", C.c_int32),
         ("cellRadius", C.c_float), ("hBS", C.c_float), ("hUT", C.c_float)]
 
 

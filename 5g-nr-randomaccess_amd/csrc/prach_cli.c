@@ -14,6 +14,8 @@
  * Extensions (not in the reference): --program beta|withnoma|noma, --rng glibc|philox, --nue N,
  * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N, --csv FILE (--program beta: the results.csv of
  * AveragePerformance.py over the --times seeds of every sweep point, written by prach_results_csv_*),
+ * --sector-grants 1 (--program withnoma) / --nonsector 1 (--program noma): the two code paths the reference carries
+ * commented out (WithNOMA:312,626-637 / NOMA.c:325-447,688);
  * --gpus N: the --times x sweep grid sharded over N devices of the node by host C — one forked child per device,
  * forked BEFORE any HIP call, trials dealt by descending cost (Philox: any trial anywhere; glibc: whole seeds, because
  * the sweep of a seed is chained through its rand() stream), results merged by the parent through shared memory; the
@@ -216,6 +218,10 @@ int main(int argc, char *argv[]) {
             want_logs = atoi(v) != 0;
         } else if (strcmp(a, "--device") == 0) {
             device = atoi(v);
+        } else if (strcmp(a, "--sector-grants") == 0) { /* the author's commented-out per-sector grant path (WithNOMA:312,626-637) */
+            if (atoi(v)) base.flags |= PRACH_FLAG_SECTOR_GRANTS;
+        } else if (strcmp(a, "--nonsector") == 0) { /* the author's commented-out cell-wide NOMA grouping (NOMA.c:688) */
+            if (atoi(v)) base.flags |= PRACH_FLAG_NOMA_NONSECTOR;
         } else if (strcmp(a, "--gpus") == 0) {
             if (atoi(v) < 1 || atoi(v) > 64) die("--gpus N: 1..64 devices of this node");
             gpus = atoi(v);

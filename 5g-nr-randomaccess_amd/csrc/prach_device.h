@@ -73,6 +73,8 @@ struct TrialDev {
     const int *n_pre0, *n_sector;
     const double *n_gain, *n_lgain;
     const unsigned *n_nd0;
+    int flags;                   // PRACH_FLAG_* (include/prach.h)
+    int *sector;                 // PRACH_FLAG_SECTOR_GRANTS: per UE, the sector drawn by activateUEs (WithNOMA:393-410); else null
 };
 
 constexpr int WG_THREADS = 1024;

@@ -86,6 +86,8 @@ struct TrialG {
     const PRACH_G int *n_pre0, *n_sector;
     const PRACH_G double *n_gain, *n_lgain;
     const PRACH_G unsigned *n_nd0;
+    int flags;
+    PRACH_G int *sector;
 
     __device__ __forceinline__ explicit TrialG(const TrialDev &d)
         : variant(d.variant), uniform(d.uniform), nUE(d.nUE), nP(d.nP), backoff(d.backoff), nGrantUL(d.nGrantUL), maxRarWindow(d.maxRarWindow),
@@ -96,7 +98,7 @@ struct TrialG {
           timers((PRACH_G int *)d.timers), out((PRACH_G DevResult *)d.out), evw(d.evw), mbstride(d.mbstride), binshift(d.binshift),
           mbox((PRACH_G int *)d.mbox), cand((PRACH_G v2i_t *)d.cand), dense_pass(d.dense_pass), pipeline(d.pipeline),
           n_pre0((const PRACH_G int *)d.n_pre0), n_sector((const PRACH_G int *)d.n_sector), n_gain((const PRACH_G double *)d.n_gain),
-          n_lgain((const PRACH_G double *)d.n_lgain), n_nd0((const PRACH_G unsigned *)d.n_nd0) {}
+          n_lgain((const PRACH_G double *)d.n_lgain), n_nd0((const PRACH_G unsigned *)d.n_nd0), flags(d.flags), sector((PRACH_G int *)d.sector) {}
 };
 
 // The hot record is read with a non-temporal 16-byte load (global_load_dwordx4 ... nt: served by L2, never

@@ -59,7 +59,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, cand;
-    size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0;
+    size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0, sector;
     size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
     int evw, mbstride;
@@ -127,6 +127,7 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         T.stream = T.stream_len ? take(4 * (T.stream_len + 2)) : 0;
         T.logs = (ue_logs && ue_logs[idx[k]]) ? take(sizeof(prach_ue_log) * n) : 0;
         T.timers = take(4 * n);
+        T.sector = (c.flags & PRACH_FLAG_SECTOR_GRANTS) ? take(4 * n) : 0;
         T.n_pre0 = T.n_sector = T.n_gain = T.n_lgain = T.n_nd0 = 0;
         if (c.variant == PRACH_VARIANT_NOMA_C) {
             T.n_pre0 = take(4 * n); T.n_sector = take(4 * n); T.n_gain = take(8 * n); T.n_lgain = take(8 * n); T.n_nd0 = take(4 * n);
@@ -274,6 +275,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         while (((c.nUE - 1) >> d.binshift) >= 1024) d.binshift++;
         d.mbox = L.mbox ? reinterpret_cast<int *>(A + L.mbox) : nullptr;
         d.cand = L.cand ? reinterpret_cast<int2 *>(A + L.cand) : nullptr;
+        d.flags = c.flags;
+        d.sector = L.sector ? reinterpret_cast<int *>(A + L.sector) : nullptr;
         int32_t *sched = reinterpret_cast<int32_t *>(H + L.sched);
         for (size_t s = 0; s < L.sched_len; s++) sched[s] = c.nUE;
         prach_arrival_schedule(&c, sched, (int)L.sched_len, &nAccess[k]);
@@ -495,6 +498,7 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
         int maxP = 1;
         for (int k : idx) {
             cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
+            cluster_ok = cluster_ok && !(cfgs[k].flags & PRACH_FLAG_SECTOR_GRANTS); // the dormant per-sector grant path runs on trial_kernel (index-ordered, exact)
             if (mode == PRACH_RNG_GLIBC) cluster_ok = cluster_ok && cfgs[k].nUE <= CLUSTER_GLIBC_MAX_UE;
             maxP = std::max(maxP, cfgs[k].nPreamble);
         }

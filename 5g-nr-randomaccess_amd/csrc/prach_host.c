@@ -53,6 +53,9 @@ int prach_cfg_validate(const prach_cfg *c) {
     if (c->rng_mode != PRACH_RNG_GLIBC && c->rng_mode != PRACH_RNG_PHILOX) return PRACH_ERR_ARG;
     if (c->nPreamble > 254 || c->maxRarWindow > 255 || c->maxMsg2TxCount > 255) return PRACH_ERR_UNSUPPORTED;
     if (c->nUE > (1 << 24)) return PRACH_ERR_UNSUPPORTED;
+    if (c->flags & ~(PRACH_FLAG_SECTOR_GRANTS | PRACH_FLAG_NOMA_NONSECTOR)) return PRACH_ERR_ARG;
+    if ((c->flags & PRACH_FLAG_SECTOR_GRANTS) && c->variant != PRACH_VARIANT_WITHNOMA_C) return PRACH_ERR_ARG; /* sectors exist in that program only */
+    if ((c->flags & PRACH_FLAG_NOMA_NONSECTOR) && c->variant != PRACH_VARIANT_NOMA_C) return PRACH_ERR_ARG;
     return PRACH_OK;
 }
 

@@ -48,7 +48,8 @@ struct Lds {
     unsigned *dead; // [DEADW_T] bitmap of 64-UE groups in which every UE has finished (skipped by every pass)
 };
 enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_FINS, S_NS, S_NRC, S_NPOST, S_STATUS, S_PTC, S_FC, S_ND_LO,
-       S_SUMT_LO = 16 /* 64-bit at [16,17] */, S_ND64 = 18 /* 64-bit at [18,19] */ };
+       S_SUMT_LO = 16 /* 64-bit at [16,17] */, S_ND64 = 18 /* 64-bit at [18,19] */,
+       S_SGC = 24 /* [24,30): sectorGrants[6], WithNOMA:260 */, S_SGN = 32 /* [32,38): singleton callers of this subframe per sector */ };
 
 __device__ __forceinline__ Lds carve(char *smem, int nP) {
     Lds L;
@@ -462,6 +463,23 @@ __device__ __forceinline__ void resolve(const TrialG &P, const Lds &L, const int
 
     // RAR grants to the first (nGrantUL-1-grantCheck) singleton callers in index order (Beta.c:336-347)
     const int ns = L.scal[S_NS];
+    if (P.flags & PRACH_FLAG_SECTOR_GRANTS) {
+        // the dormant per-sector grant test (WithNOMA:626-637 with the call of :312): every 60-degree sector has its own budget,
+        // grantCheck[sector] counts that sector's singleton callers of the 5 ms window
+        for (int j = tid; j < ns; j += WG_THREADS) {
+            const int my = sing[j];
+            const int sj = P.sector[my];
+            int rank = 0;
+            for (int m = 0; m < ns; m++) { const int o = sing[m]; rank += (o < my && P.sector[o] == sj) ? 1 : 0; }
+            if (rank < P.nGrantUL - 1 - L.scal[S_SGC + sj]) grant_rec(&P.rec[my]);
+            atomicAdd(&L.scal[S_SGN + sj], 1);
+        }
+        __syncthreads();
+        if (tid < 6) { L.scal[S_SGC + tid] += L.scal[S_SGN + tid]; L.scal[S_SGN + tid] = 0; }
+        for (int k = tid; k < NW * nP; k += WG_THREADS) { L.wavehist[k] = 0; L.smidx[k] = INT_MAX; }
+        __syncthreads();
+        return;
+    }
     const int G = max(0, P.nGrantUL - 1 - grantCheck);
     for (int j = tid; j < ns; j += WG_THREADS) {
         const int my = sing[j];
@@ -507,9 +525,29 @@ __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__res
     for (int t = 0; t < P.stop; t++) {
         steps++;
         tlast = t;
-        if (t % 5 == 0) grantCheck = 0; // Beta.c:112 (hard-coded 5)
+        if (t % 5 == 0) { // Beta.c:112 (hard-coded 5); WithNOMA:268-274
+            grantCheck = 0;
+            if ((P.flags & PRACH_FLAG_SECTOR_GRANTS) && threadIdx.x < 6) L.scal[S_SGC + threadIdx.x] = 0; // (a barrier follows in the pass)
+        }
         const int prevAC = activeCheck;
         if (t % aT == 0 && activeCheck != nUE) activeCheck = P.sched[t / aT]; // Beta.c:121-134
+        if ((P.flags & PRACH_FLAG_SECTOR_GRANTS) && activeCheck > prevAC) {
+            // activateUEs (WithNOMA:393-410): theta from the first of the two activation draws fixes the UE's sector (r is never read)
+            for (int i = prevAC + (int)threadIdx.x; i < activeCheck; i += WG_THREADS) {
+                const int d = GLIBC ? P.stream[base + 2ull * (unsigned long long)(i - prevAC)]
+                                    : philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, 0u, (unsigned)nUE, (unsigned)P.variant);
+                const float pi = 3.14f;
+                const float theta = (float)d / (float)2147483647 * 2 * pi;
+                int sec;
+                if (theta >= 0 && theta < ((1. / 3.) * pi)) sec = 0;
+                else if (theta >= ((1. / 3.) * pi) && theta < ((2. / 3.) * pi)) sec = 1;
+                else if (theta >= ((2. / 3.) * pi) && theta < 3.14) sec = 2;
+                else if (theta >= pi && theta < ((4. / 3.) * pi)) sec = 3;
+                else if (theta >= ((4. / 3.) * pi) && theta < ((5. / 3.) * pi)) sec = 4;
+                else sec = 5;
+                P.sector[i] = sec;
+            }
+        }
         if (GLIBC) {
             const unsigned long long actdraws =
                 P.variant == PRACH_VARIANT_WITHNOMA_C ? 2ull * (unsigned long long)(activeCheck - prevAC) : 0ull;

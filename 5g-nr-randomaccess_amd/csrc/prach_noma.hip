@@ -122,6 +122,11 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     // msg2Results SETS rarWindow to the literal 5 and then compares it with maxRarWindow (NOMA.c:453-455): with
     // maxRarWindow > 5 a failed transmitter is never rescheduled (txTime += 3 and rarWindow = 5 is all that happens)
     const bool rar_expires = 5 >= P.maxRarWindow;
+    // PRACH_FLAG_NOMA_NONSECTOR: the cell-wide grouping preambleCollisionDetection (NOMA.c:325-447; its call at NOMA.c:688 is commented
+    // out in the reference): ONE group with ONE budget of nGrantUL per access slot instead of six; a pair whose decode draw says
+    // "one of the two" always decodes the weaker UE, without the second draw (NOMA.c:413-415 vs :287-290)
+    const bool nonsector = (P.flags & PRACH_FLAG_NOMA_NONSECTOR) != 0;
+    const int nsect = nonsector ? 1 : 6;
 
     // pass A for one UE of the slot whose subframe is tA: activation of the newly arrived (activeUE, NOMA.c:131-140: everything
     // else comes from the activation table) and the transmitter gather (NOMA.c:207: RA==0, txTime==time+1, msg2==0,
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
         }
         const unsigned pk = (unsigned)r.w;
         if (i < acA && (pk & 3) == 1 && !(pk & (N_RA_BIT | N_FAIL_BIT | N_MSG2_BIT)) && r.x == tA + 1 && now_backoff(r.z, tA) <= 0) {
-            const int bin = sector[i] * nP + (int)((pk >> N_PRE_SHIFT) & 0xff);
+            const int bin = (nonsector ? 0 : sector[i]) * nP + (int)((pk >> N_PRE_SHIFT) & 0xff);
             atomicAdd(&L.cnt[bin], 1);
             atomicMin(&L.who[bin], i);
         }
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
         if (nsucc_tot == nUE) { time_exit = maxt_tot; all_done = true; break; } // NOMA.c:707-710: `time` of the last success
 
         // ---- resolve: one wavefront per sector (NOMA.c:214-309), identical on every workgroup ----
-        if (w < 6) {
+        if (w < nsect) {
             const int sct = w;
             const bool single = lane < nP && L.tcnt[sct * nP + lane] == 1;
             const int myidx = single ? L.twho[sct * nP + lane] : -1;
@@ -260,9 +265,12 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                             int decoded = 2; // both
                             npd++;
                             if (d1 <= 644245094) { // (double)rand()/RAND_MAX < 0.3 (NOMA.c:284-285)
-                                const int d2 = philox_draw31(P.seed_lo, P.seed_hi, 0xFFFFFFFFu, kd + 1, (unsigned)nUE, NOMA_VARIANT);
-                                decoded = d2 % 2; // index into rx[] = {low, high}
-                                npd++;
+                                if (nonsector) decoded = 0; // rx[0], the weaker UE: NOMA.c:413-415
+                                else {
+                                    const int d2 = philox_draw31(P.seed_lo, P.seed_hi, 0xFFFFFFFFu, kd + 1, (unsigned)nUE, NOMA_VARIANT);
+                                    decoded = d2 % 2; // index into rx[] = {low, high}
+                                    npd++;
+                                }
                             }
                             if ((lane == i && (decoded == 2 || decoded == 0)) || (lane == j && (decoded == 2 || decoded == 1))) grantme = true;
                         }

@@ -31,6 +31,13 @@ extern "C" {
 #define PRACH_VARIANT_WITHNOMA_C  1 /* RandomAccessWithNOMA.c      */
 #define PRACH_VARIANT_NOMA_C      2 /* NOMA.c (sector power-level grouping) */
 
+/* prach_cfg.flags: variants the reference carries as commented-out code (never executed by the programs as committed) */
+#define PRACH_FLAG_SECTOR_GRANTS   1 /* WITHNOMA_C: one UL-grant budget per 60-degree sector (sectorGrants[6], RandomAccessWithNOMA.c:260,
+                                        271-273; the call of :312 and the grantCheck[sector] test of :626-637 un-commented); the sector
+                                        comes from activateUEs' first draw (WithNOMA:393-410) */
+#define PRACH_FLAG_NOMA_NONSECTOR  2 /* NOMA_C: the cell-wide grouping preambleCollisionDetection (NOMA.c:325-447, call of :688
+                                        un-commented) instead of preambleSectorCollisionDetection: one nGrantUL budget per access slot */
+
 #define PRACH_RNG_GLIBC  0 /* the reference's own draw stream: srand(seed)/rand(), bit-exact vs the reference */
 #define PRACH_RNG_PHILOX 1 /* Philox4x32-10, counter = (ue, draw#, nUE, variant), key = seed */
 
@@ -63,7 +70,7 @@ typedef struct prach_cfg {
                                (the reference seeds once per seed and lets the stream run on across
                                the nUE sweep: Beta.c:66-71) */
     int32_t max_steps;      /* 0 = run to maxTime; >0 = stop after that many subframes */
-    int32_t reserved;
+    int32_t flags;          /* PRACH_FLAG_*: code paths the reference's author left commented out */
     float cellRadius, hBS, hUT; /* parsed by the CLI, never read by the simulation (WithNOMA:80-82);
                                    NOMA_C: cellRadius scales the UE drop (NOMA.c:56,168) */
 } prach_cfg;

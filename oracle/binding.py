@@ -20,7 +20,7 @@ SCAN_SETS, SCAN_LITERAL = 0, 1
 class OracleCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "variant", "uniform", "nUE", "nPreamble", "backoff", "nGrantUL", "maxRarWindow",
-        "maxMsg2TxCount", "accessTime", "scan_mode", "max_steps")]
+        "maxMsg2TxCount", "accessTime", "scan_mode", "max_steps", "sector_grants")]
 
 
 UE_FIELDS = ("idx", "timer", "active", "txTime", "firstTxTime", "secondTxTime", "nowBackoff", "preamble",
@@ -86,11 +86,11 @@ def lib():
 
 
 def make_cfg(nUE, variant=VARIANT_BETA_C, uniform=0, nPreamble=54, backoff=20, nGrantUL=None, maxRarWindow=6,
-             maxMsg2TxCount=9, accessTime=5, scan_mode=SCAN_SETS, max_steps=0) -> OracleCfg:
+             maxMsg2TxCount=9, accessTime=5, scan_mode=SCAN_SETS, max_steps=0, sector_grants=0) -> OracleCfg:
     if nGrantUL is None:
         nGrantUL = 54 if variant == VARIANT_BETA_C else 12  # Beta.c:49 / WithNOMA:73
     return OracleCfg(variant, uniform, nUE, nPreamble, backoff, nGrantUL, maxRarWindow, maxMsg2TxCount, accessTime,
-                     scan_mode, max_steps)
+                     scan_mode, max_steps, sector_grants)
 
 
 class Rng:
@@ -179,7 +179,7 @@ def model_run_trial(cfg: OracleCfg, rng_mode, seed, stream=None, stream_off=0, n
 
 class NomaCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nUE", "nPreamble", "backoff", "nGrantUL", "maxRarWindow", "maxMsg1ReTx",
-                                         "accessTime", "max_steps")] + [("cellRadius", C.c_float)]
+                                         "accessTime", "max_steps", "nonsector")] + [("cellRadius", C.c_float)]
 
 
 class NomaResult(C.Structure):
@@ -199,8 +199,8 @@ class NomaUE(C.Structure):
 
 
 def make_noma_cfg(nUE, nPreamble=54, backoff=20, nGrantUL=2, maxRarWindow=5, maxMsg1ReTx=10, accessTime=5, max_steps=0,
-                  cellRadius=500.0) -> NomaCfg:
-    return NomaCfg(nUE, nPreamble, backoff, nGrantUL, maxRarWindow, maxMsg1ReTx, accessTime, max_steps, cellRadius)
+                  cellRadius=500.0, nonsector=0) -> NomaCfg:
+    return NomaCfg(nUE, nPreamble, backoff, nGrantUL, maxRarWindow, maxMsg1ReTx, accessTime, max_steps, nonsector, cellRadius)
 
 
 def noma_run_trial(cfg: NomaCfg, rng: Rng, want_ues=True):

@@ -115,22 +115,29 @@ static void preambleSectorCollisionDetection(nctx_t *c, int activeCheck, int tim
     const int nP = k->nPreamble, nGrantUL = k->nGrantUL;
     tx_t txUEs[256];
     (void)tmpIdx;
+    /* k->nonsector: the cell-wide variant preambleCollisionDetection (NOMA.c:325-447; its call at NOMA.c:688 is commented out in
+     * the reference): ONE group and ONE grant budget; it differs from the per-sector function in exactly two more places, marked below */
+    const int nonsector = k->nonsector != 0, nsect = nonsector ? 1 : 6;
     /* per (sector, preamble): count and the (only relevant) member when count == 1 */
     memset(cnt, 0, sizeof(int) * 6 * (size_t)nP);
     for (int i = 0; i < activeCheck; i++) {
         if (user[i].RA == 0 && user[i].txTime == time + 1 && user[i].msg2 == 0 && user[i].nowBackoff <= 0 && user[i].RaFailed == 0) {
-            int b = user[i].sector * nP + user[i].preamble;
+            int b = (nonsector ? 0 : user[i].sector) * nP + user[i].preamble; /* (NOMA.c:332 also asks active == 1: implied by txTime == time + 1) */
             if (cnt[b]++ == 0) who[b] = i;
         }
     }
-    for (int s = 0; s < 6; s++) {
+    for (int s = 0; s < nsect; s++) {
         int count = 0;
         for (int p = 0; p < nP; p++)
             if (cnt[s * nP + p] == 1) { txUEs[count].idx = who[s * nP + p]; txUEs[count].channelGain = user[who[s * nP + p]].channelGain; count++; }
         if (count <= 0) continue;
         if (count <= nGrantUL) {
-            for (int i = 0; i < count; i++)
-                if (grantCheck[s] < nGrantUL) { grantCheck[s]++; user[txUEs[i].idx].msg2 = 1; }
+            for (int i = 0; i < count; i++) {
+                if (nonsector) { /* NOMA.c:377-382: msg2 = 1 sits OUTSIDE the budget test */
+                    if (grantCheck[s] < nGrantUL) grantCheck[s]++;
+                    user[txUEs[i].idx].msg2 = 1;
+                } else if (grantCheck[s] < nGrantUL) { grantCheck[s]++; user[txUEs[i].idx].msg2 = 1; } /* NOMA.c:245-250 */
+            }
         } else {
             for (int i = 0; i < count; i++) /* sortUE: bubble sort, strict < (stable), NOMA.c:90-103 */
                 for (int j = 0; j < count - 1; j++)
@@ -149,8 +156,11 @@ static void preambleSectorCollisionDetection(nctx_t *c, int activeCheck, int tim
                             grantCheck[s]++;
                             double p = (double)pair_draw(c, time / k->accessTime, s, gi, 0) / (double)2147483647;
                             if (p < 0.3) {
-                                int randomUE = pair_draw(c, time / k->accessTime, s, gi, 1) % 2;
-                                user[rx[randomUE]].msg2 = 1;
+                                if (nonsector) user[rx[0]].msg2 = 1; /* NOMA.c:413-415: always the weaker UE, no second draw */
+                                else {
+                                    int randomUE = pair_draw(c, time / k->accessTime, s, gi, 1) % 2; /* NOMA.c:287-290 */
+                                    user[rx[randomUE]].msg2 = 1;
+                                }
                             } else {
                                 user[rx[0]].msg2 = 1;
                                 user[rx[1]].msg2 = 1;

@@ -48,6 +48,7 @@ void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 typedef struct {
     oracle_ue u;
     int32_t raFailed;   /* Beta.c:24, never set to -1 (assignment commented out, Beta.c:252) */
+    int32_t sector;     /* WithNOMA:398-410 (only read by the dormant per-sector grant test, WithNOMA:626-637) */
     uint32_t ndraw;     /* philox: per-UE draw index */
 } ue_t;
 
@@ -298,12 +299,17 @@ int oracle_run_trial(const oracle_cfg *cfg, oracle_rng *rng, oracle_result *res,
         if (nAccessUE <= 0) nAccessUE = 1;
     }
     int nSuccessUE = 0, activeCheck = 0, grantCheck = 0, time;
+    int sectorGrants[6] = {0, 0, 0, 0, 0, 0}; /* WithNOMA:260 */
+    const int per_sector = withnoma && cfg->sector_grants;
     uint64_t steps = 0;
     const int stop = (cfg->max_steps > 0 && cfg->max_steps < maxTime) ? cfg->max_steps : maxTime;
 
     for (time = 0; time < stop; time++) {
         steps++;
-        if (time % 5 == 0) grantCheck = 0; /* Beta.c:112 — hard-coded 5 */
+        if (time % 5 == 0) { /* Beta.c:112 — hard-coded 5; WithNOMA:268-274 */
+            grantCheck = 0;
+            for (int s = 0; s < 6; s++) sectorGrants[s] = 0;
+        }
         if (activeCheck >= nUE) activeCheck = nUE;
         if (time % accessTime == 0 && activeCheck != nUE) { /* Beta.c:121-147 */
             if (cfg->uniform) {
@@ -322,9 +328,18 @@ int oracle_run_trial(const oracle_cfg *cfg, oracle_rng *rng, oracle_result *res,
                     u->timer = 0;
                     u->msg2Flag = 0;
                     u->firstTxTime = time + 1;
-                    if (withnoma) { /* activateUEs draws theta and r: WithNOMA:393-394 (values unused) */
+                    if (withnoma) { /* activateUEs draws theta and r: WithNOMA:393-394 (r is never read; theta only fixes the sector) */
+                        const float pi = 3.14;
+                        float theta = (float)draw(&c, &c.UE[i]) / (float)(2147483647) * 2 * pi;
                         (void)draw(&c, &c.UE[i]);
-                        (void)draw(&c, &c.UE[i]);
+                        int sec; /* WithNOMA:398-410 */
+                        if (theta >= 0 && theta < ((1. / 3.) * pi)) sec = 0;
+                        else if (theta >= ((1. / 3.) * pi) && theta < ((2. / 3.) * pi)) sec = 1;
+                        else if (theta >= ((2. / 3.) * pi) && theta < 3.14) sec = 2;
+                        else if (theta >= pi && theta < ((4. / 3.) * pi)) sec = 3;
+                        else if (theta >= ((4. / 3.) * pi) && theta < ((5. / 3.) * pi)) sec = 4;
+                        else sec = 5;
+                        c.UE[i].sector = sec;
                     }
                 }
             }
@@ -346,7 +361,8 @@ int oracle_run_trial(const oracle_cfg *cfg, oracle_rng *rng, oracle_result *res,
                 if (withnoma) { /* WithNOMA:307-315 */
                     if (u->active == 1 && u->msg2Flag == 0) {
                         selectPreamble(&c, user, time);
-                        if (u->txTime == time) preambleCollision(&c, i, time, &grantCheck);
+                        /* WithNOMA:312 (the author's commented-out call) passes sectorGrants, WithNOMA:626-637 indexes it by the caller's sector */
+                        if (u->txTime == time) preambleCollision(&c, i, time, per_sector ? &sectorGrants[user->sector] : &grantCheck);
                     }
                 } else { /* Beta.c:155-164 */
                     if (u->active == 1 && u->msg2Flag == 0) selectPreamble(&c, user, time);

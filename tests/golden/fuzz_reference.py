@@ -21,11 +21,14 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-BIN = os.path.join(ROOT, "oracle", "_ref", "RandomAccessWithNOMA")
-RUNS = os.path.join(ROOT, "oracle", "_ref", "runs", "fuzz")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_fuzz.json")
+# PRACH_FUZZ_VARIANT=sector: the same for oracle/_ref/RandomAccessWithNOMA_sector — the reference with the author's own
+# commented-out per-sector grant lines enabled by the sed recipe in oracle/Makefile -> ref_fuzz_sector.json
+VARIANT = os.environ.get("PRACH_FUZZ_VARIANT", "")
+BIN = os.path.join(ROOT, "oracle", "_ref", "RandomAccessWithNOMA" + ("_sector" if VARIANT == "sector" else ""))
+RUNS = os.path.join(ROOT, "oracle", "_ref", "runs", "fuzz" + ("_sector" if VARIANT == "sector" else ""))
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_fuzz_sector.json" if VARIANT == "sector" else "ref_fuzz.json")
 KEEP = 3
-SEED = 4242
+SEED = 4242 if VARIANT != "sector" else 5151
 
 
 def flag_sets(n):
@@ -104,7 +107,8 @@ def main():
             blocks.append("\n".join(cur) + "\n")
         r["stdout_blocks"] = blocks[:len(r["trials"])]
     json.dump({"generated_by": "tests/golden/fuzz_reference.py (reference compiled from /root/reference)", "seed": SEED,
-               "program": "RandomAccessWithNOMA", "variant": "WITHNOMA_C", "runs": kept}, open(OUT, "w"), indent=1)
+               "program": "RandomAccessWithNOMA" + (" + per-sector grant lines un-commented (oracle/Makefile SED_SECTOR_GRANTS)" if VARIANT == "sector" else ""),
+               "variant": "WITHNOMA_C", "sector_grants": int(VARIANT == "sector"), "runs": kept}, open(OUT, "w"), indent=1)
     print(f"{len(kept)} of {n} runs finished at least one sweep point in {budget:.0f} s; wrote {OUT}")
 
 

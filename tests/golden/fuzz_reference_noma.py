@@ -16,11 +16,14 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-BIN = os.path.join(ROOT, "oracle", "_ref", "NOMA_params")
-RUNS = os.path.join(ROOT, "oracle", "_ref", "runs", "fuzz_noma")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_fuzz_noma.json")
+# PRACH_FUZZ_VARIANT=nonsector: the same for oracle/_ref/NOMA_nonsector_params — NOMA.c with the author's commented-out
+# cell-wide grouping call enabled by the sed recipe in oracle/Makefile -> ref_fuzz_noma_nonsector.json
+VARIANT = os.environ.get("PRACH_FUZZ_VARIANT", "")
+BIN = os.path.join(ROOT, "oracle", "_ref", "NOMA_nonsector_params" if VARIANT == "nonsector" else "NOMA_params")
+RUNS = os.path.join(ROOT, "oracle", "_ref", "runs", "fuzz_noma" + ("_nonsector" if VARIANT == "nonsector" else ""))
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_fuzz_noma_nonsector.json" if VARIANT == "nonsector" else "ref_fuzz_noma.json")
 KEEP = 4
-SEED = 777
+SEED = 777 if VARIANT != "nonsector" else 888
 
 
 def param_sets(n):
@@ -63,7 +66,8 @@ def main():
         runs = list(ex.map(lambda kv: run_one(kv[0], kv[1], budget), enumerate(param_sets(n))))
     kept = [r for r in runs if r["lines"]]
     json.dump({"generated_by": "tests/golden/fuzz_reference_noma.py (reference NOMA.c compiled from /root/reference + oracle/noma_params_main.c)",
-               "seed": SEED, "program": "NOMA", "variant": "NOMA_C", "runs": kept}, open(OUT, "w"), indent=1)
+               "seed": SEED, "program": "NOMA" + (" + cell-wide grouping call un-commented (oracle/Makefile SED_NONSECTOR_NOMA)" if VARIANT == "nonsector" else ""),
+               "variant": "NOMA_C", "nonsector": int(VARIANT == "nonsector"), "runs": kept}, open(OUT, "w"), indent=1)
     print(f"{len(kept)} of {n} runs finished at least one sweep point in {budget:.0f} s; wrote {OUT}")
 
 

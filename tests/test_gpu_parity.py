@@ -623,6 +623,41 @@ def test_gpu_reproduces_reference_random_flags(pkg, engine):
     assert checked >= 170
 
 
+def test_gpu_sector_grants_variant(pkg, ob, engine):
+    """PRACH_FLAG_SECTOR_GRANTS — the per-sector UL-grant path the reference's author left commented out
+    (RandomAccessWithNOMA.c:260,271-273,312,626-637).  (1) glibc mode against the PATCHED reference's own files
+    (tests/golden/ref_fuzz_sector.json: the reference compiled with exactly those lines swapped in, oracle/Makefile
+    SED_SECTOR_GRANTS): Results.txt, printed block and Logs.txt SHA-256 of every finished sweep point, byte for byte;
+    (2) both RNG modes against the oracle, every logged field of every UE."""
+    import json
+    fz = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fuzz_sector.json")))
+    checked = 0
+    for r in fz["runs"]:
+        off = 0
+        for k, tr in enumerate(r["trials"]):
+            cfg = pkg.make_cfg(tr["nUE"], variant=1, rng_mode=pkg.RNG_GLIBC, seed=0, stream_offset=off, flags=pkg.FLAG_SECTOR_GRANTS, **r["cfg_overrides"])
+            (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+            what = (r["argv"], tr["nUE"])
+            assert res.status == 0, what
+            off += res.draws
+            assert pkg.format_results(cfg, res, 0.0).decode() == tr["results_text"], what
+            so = pkg.format_stdout(cfg, res, 0.0).decode()
+            so = "".join(l + "\n" for l in so.split("\n") if l and not l.startswith("Latency:"))
+            assert so == r["stdout_blocks"][k], what
+            text = pkg.format_logs(logs, tr["nUE"])
+            assert len(text) == tr["logs_bytes"] and hashlib.sha256(text).hexdigest() == tr["logs_sha256"], what
+            checked += 1
+    assert checked >= 20
+    for rng_mode, nUE, kw in ((1, 30000, {}), (0, 12000, dict(nGrantUL=3)), (1, 9000, dict(nGrantUL=2, nPreamble=16, backoff=5)),
+                              (1, 5000, dict(uniform=1, nGrantUL=2)), (1, 65, {})):
+        cfg = pkg.make_cfg(nUE, variant=1, rng_mode=rng_mode, seed=77, flags=pkg.FLAG_SECTOR_GRANTS, **kw)
+        (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+        ores, oues = ob.run_trial(ob.make_cfg(nUE, variant=1, sector_grants=1, **kw), ob.Rng(rng_mode, 77))
+        assert_same(pkg, res, logs, ores, oues, ("sector", rng_mode, nUE, kw))
+    with pytest.raises(pkg.PrachError):  # sectors exist in RandomAccessWithNOMA.c only
+        engine.run_trials([pkg.make_cfg(1000, variant=0, flags=pkg.FLAG_SECTOR_GRANTS)])
+
+
 def test_dense_pass_option_agrees(pkg, ob, engine):
     """engine option "dense": the cluster kernel without the compacted two-phase pass (every group through the full
     per-UE body) gives the same trial, bit for bit."""

@@ -188,3 +188,63 @@ def test_noma_oracle_reproduces_reference_random_parameters(ob):
     out = _pool_map(run, fz["runs"])
     assert sum((b for b, _ in out), []) == []
     assert sum(c for _, c in out) == sum(len(r["lines"]) for r in fz["runs"]) >= 190
+
+
+def test_noma_oracle_nonsector_reproduces_patched_reference(ob):
+    """NOMA.c's cell-wide grouping preambleCollisionDetection (NOMA.c:325-447), whose call the author left commented
+    out (NOMA.c:688).  Pin = the reference compiled with lines 688 / 689 swapped by the sed recipe of oracle/Makefile
+    (SED_NONSECTOR_NOMA) and its file-scope parameters set by oracle/noma_params_main.c (tests/golden/fuzz_reference_noma.py,
+    PRACH_FUZZ_VARIANT=nonsector): every line the patched program printed, glibc stream chained over the sweep."""
+    import json
+    import os
+    fz = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fuzz_noma_nonsector.json")))
+    assert fz["nonsector"] == 1 and len(fz["runs"]) >= 16
+
+    def run(r):
+        rng, rng6 = ob.Rng(ob.RNG_GLIBC, 0), ob.Rng(ob.RNG_GLIBC, 0)
+        bad, checked, differs = [], 0, 0
+        for k, line in enumerate(r["lines"]):
+            n = 10000 * (k + 1)
+            cfg = ob.make_noma_cfg(n, nonsector=1, **r["cfg_overrides"])
+            res, _ = ob.noma_run_trial(cfg, rng, want_ues=False)
+            if ob.noma_format_line(cfg, res).decode().strip() != line:
+                bad.append((r["argv"], n))
+            checked += 1
+            if k == 0:  # the per-sector grouping gives another trial
+                cfg6 = ob.make_noma_cfg(n, **r["cfg_overrides"])
+                res6, _ = ob.noma_run_trial(cfg6, rng6, want_ues=False)
+                differs += ob.noma_format_line(cfg6, res6).decode().strip() != line
+        return bad, checked, differs
+
+    out = _pool_map(run, fz["runs"])
+    assert sum((b for b, _, _ in out), []) == []
+    assert sum(c for _, c, _ in out) == sum(len(r["lines"]) for r in fz["runs"]) >= 40
+    assert sum(d for _, _, d in out) >= len(fz["runs"]) // 2
+
+
+@pytest.mark.gpu
+def test_gpu_noma_nonsector_equals_oracle(pkg, ob, engine):
+    """PRACH_FLAG_NOMA_NONSECTOR on the GPU (one resolver wavefront, one grant budget per access slot) == the oracle's
+    cell-wide grouping, aggregates and every logged field of every UE, for several cluster sizes."""
+    cases = [(20000, 1, {}), (100000, 2, {}), (6000, 3, dict(nGrantUL=5, nPreamble=64)), (9000, 4, dict(nGrantUL=1, backoff=7)),
+             (64, 5, dict(nGrantUL=30)), (12000, 6, dict(nPreamble=8, nGrantUL=3, accessTime=3))]
+    for G in (0, 1, 8):
+        engine.set("cluster", G)
+        try:
+            for nUE, seed, kw in cases:
+                cfg = pkg.make_cfg(nUE, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=seed, flags=pkg.FLAG_NOMA_NONSECTOR, **kw)
+                (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+                ocfg = ob.make_noma_cfg(nUE, nonsector=1, **kw)
+                ores, oues = ob.noma_run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, seed))
+                assert (res.status, res.nSuccessUE, res.sumTimer, res.preambleTxCount, res.failCounts, res.activeCheck, res.draws, res.time_exit) == \
+                       (0, ores.nSuccessUE, ores.delay, ores.nTxP, ores.raFailedUEs, ores.activeCheck, ores.draws, ores.time_exit), (G, nUE, kw)
+                a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16)
+                b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
+                assert (a == b).all(), (G, nUE, kw)
+                o6, _ = ob.noma_run_trial(ob.make_noma_cfg(nUE, **kw), ob.Rng(ob.RNG_PHILOX, seed), want_ues=False)
+                if nUE >= 6000:
+                    assert (o6.nSuccessUE, o6.delay) != (ores.nSuccessUE, ores.delay)  # not the per-sector trial
+        finally:
+            engine.set("cluster", 0)
+    with pytest.raises(pkg.PrachError):  # the flag belongs to NOMA_C
+        engine.run_trials([pkg.make_cfg(1000, variant=pkg.VARIANT_BETA_C, flags=pkg.FLAG_NOMA_NONSECTOR)])

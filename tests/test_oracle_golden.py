@@ -98,3 +98,34 @@ def test_oracle_reproduces_reference_random_flags(ob):
             assert hashlib.sha256(logs).hexdigest() == tr["logs_sha256"], what
             checked += 1
     assert checked >= 45
+
+
+def test_oracle_sector_grants_reproduces_patched_reference(ob):
+    """the per-sector UL-grant path the reference's author left commented out (RandomAccessWithNOMA.c:260,271-273:
+    sectorGrants[6]; :312 the call that passes it; :626-637 the grantCheck[sector] test).  Pin = the reference compiled with
+    exactly those lines swapped in by the sed recipe of oracle/Makefile (SED_SECTOR_GRANTS; the source streams from
+    /root/reference into the compiler, no edited copy exists), run under random flag sets by tests/golden/fuzz_reference.py
+    (PRACH_FUZZ_VARIANT=sector): Results.txt bytes, printed block and SHA-256 of the per-UE Logs.txt of every finished sweep
+    point, the rand() stream carried across the sweep.  Default: the first point of every run; PRACH_FULL_GOLDEN=1: all."""
+    import json
+    fz = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fuzz_sector.json")))
+    assert fz["sector_grants"] == 1 and len(fz["runs"]) >= 12
+    checked = differs = 0
+    for r in fz["runs"]:
+        rng = ob.Rng(ob.RNG_GLIBC, 0)
+        for k, tr in enumerate(r["trials"]):
+            if not FULL and (k > 0 or (r["cfg_overrides"]["uniform"] and r["run"] % 2 != 0)):
+                break
+            cfg = ob.make_cfg(tr["nUE"], variant=ob.VARIANT_WITHNOMA_C, sector_grants=1, **r["cfg_overrides"])
+            res, ues = ob.run_trial(cfg, rng)
+            what = (r["argv"], tr["nUE"])
+            assert ob.format_results(cfg, res).decode() == tr["results_text"], what
+            assert ob.format_stdout(cfg, res).decode() == r["stdout_blocks"][k], what
+            logs = ob.format_logs(ues, cfg.nUE)
+            assert len(logs) == tr["logs_bytes"] and hashlib.sha256(logs).hexdigest() == tr["logs_sha256"], what
+            checked += 1
+            if k == 0:  # ... and the variant is not a no-op: with one cell-wide budget the same trial ends differently
+                cfg0 = ob.make_cfg(tr["nUE"], variant=ob.VARIANT_WITHNOMA_C, **r["cfg_overrides"])
+                res0, _ = ob.run_trial(cfg0, ob.Rng(ob.RNG_GLIBC, 0), want_ues=False)
+                differs += ob.format_results(cfg0, res0).decode() != tr["results_text"]
+    assert checked >= 8 and differs >= 3  # (at the first, lightly loaded sweep point the budgets rarely bind)
