@@ -16,6 +16,7 @@
  * AveragePerformance.py over the --times seeds of every sweep point, written by prach_results_csv_*),
  * --sector-grants 1 (--program withnoma) / --nonsector 1 (--program noma): the two code paths the reference carries
  * commented out (WithNOMA:312,626-637 / NOMA.c:325-447,688);
+ * --devices LIST: the same with explicit HIP ordinals (an ordinal may repeat);
  * --gpus N: the --times x sweep grid sharded over N devices of the node by host C — one forked child per device,
  * forked BEFORE any HIP call, trials dealt by descending cost (Philox: any trial anywhere; glibc: whole seeds, because
  * the sweep of a seed is chained through its rand() stream), results merged by the parent through shared memory; the
@@ -156,7 +157,8 @@ static int run_worker(int device, const prach_cfg *cfgs, const int *idx, int m, 
 int main(int argc, char *argv[]) {
     int randomMax = 1, variant = PRACH_VARIANT_WITHNOMA_C, rng = PRACH_RNG_GLIBC, device = 0, want_logs = 1, gpus = 1;
     int sweep_lo = 10000, sweep_hi = 100000, sweep_step = 10000; /* WithNOMA:221 */
-    const char *outdir = ".", *csv_path = NULL;
+    const char *outdir = ".", *csv_path = NULL, *devlist = NULL;
+    int devs[64];
     /* --program must be known before the defaults are laid down */
     for (int i = 1; i + 1 < argc; i += 2)
         if (strcmp(argv[i], "--program") == 0)
@@ -225,6 +227,8 @@ int main(int argc, char *argv[]) {
         } else if (strcmp(a, "--gpus") == 0) {
             if (atoi(v) < 1 || atoi(v) > 64) die("--gpus N: 1..64 devices of this node");
             gpus = atoi(v);
+        } else if (strcmp(a, "--devices") == 0) { /* explicit HIP ordinals, e.g. 0,2,3 (an ordinal may repeat: workers then share that device) */
+            devlist = v;
         } else if (strcmp(a, "--csv") == 0) {
             csv_path = v;
         } else {
@@ -262,6 +266,17 @@ int main(int argc, char *argv[]) {
     }
 
     /* deal the trials to the workers: longest first onto the least loaded (cost = nUE x subframes); glibc mode deals whole seeds */
+    if (devlist) {
+        gpus = 0;
+        for (const char *q = devlist; *q && gpus < 64;) {
+            devs[gpus++] = atoi(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        if (gpus < 1) die("--devices LIST: comma-separated HIP ordinals");
+    } else {
+        for (int w = 0; w < 64; w++) devs[w] = device + w;
+    }
     if (gpus > ntr) gpus = ntr;
     if (glibc && gpus > randomMax) gpus = randomMax;
     int **widx = (int **)calloc((size_t)gpus, sizeof(int *));
@@ -288,7 +303,7 @@ int main(int argc, char *argv[]) {
     }
 
     if (gpus == 1) {
-        int rcw = run_worker(device, cfgs, widx[0], wn[0], res, lat, want_logs, outdir, glibc, npts);
+        int rcw = run_worker(devs[0], cfgs, widx[0], wn[0], res, lat, want_logs, outdir, glibc, npts);
         if (rcw) return rcw;
     } else {
         /* one child per device, forked BEFORE this process touches HIP (a forked copy of an initialised runtime is not usable) */
@@ -297,13 +312,13 @@ int main(int argc, char *argv[]) {
         for (int w = 0; w < gpus; w++) {
             pid[w] = fork();
             if (pid[w] < 0) { perror("prach_sim: fork"); return 2; }
-            if (pid[w] == 0) _exit(run_worker(device + w, cfgs, widx[w], wn[w], res, lat, want_logs, outdir, glibc, npts));
+            if (pid[w] == 0) _exit(run_worker(devs[w], cfgs, widx[w], wn[w], res, lat, want_logs, outdir, glibc, npts));
         }
         int bad = 0;
         for (int w = 0; w < gpus; w++) {
             int st = 0;
             if (waitpid(pid[w], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-                fprintf(stderr, "prach_sim: the worker of device %d failed\n", device + w);
+                fprintf(stderr, "prach_sim: the worker of device %d failed\n", devs[w]);
                 bad = 1;
             }
         }

@@ -615,6 +615,13 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         LSTAMP(1); // phase B
         __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
         LSTAMP(2);
+        // publish, first part: per bucket {histogram, lowest caller} — complete since S1; the header (event count) follows the leaver
+        // filter.  Self-validating granules: the earlier they leave, the fewer of them the other workgroups have to read twice.
+        if (tid >= WG_THREADS - 64 && tid - (WG_THREADS - 64) < nP) { // (the last wavefront: the first ones run the leaver filter)
+            const int k = tid - (WG_THREADS - 64);
+            const int ml = min(LI(lo::PAR + pc + lo::P_MLOC)[k], LI(lo::PAR + pc + lo::P_MLOCS)[k]);
+            lst(mygr + 1 + k, lmk((unsigned)LI(lo::PAR + pc + lo::P_HIST)[k], ml == INT_MAX ? GRL_NONE : (unsigned)ml, tag));
+        }
 
         // early leavers below this workgroup's lowest caller are the only ones a rank can need
         {
@@ -633,10 +640,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         __syncthreads(); // S2
         LSTAMP(4);
         // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
-        if (tid < nP) {
-            const int ml = min(LI(lo::PAR + pc + lo::P_MLOC)[tid], LI(lo::PAR + pc + lo::P_MLOCS)[tid]);
-            lst(mygr + 1 + tid, lmk((unsigned)LI(lo::PAR + pc + lo::P_HIST)[tid], ml == INT_MAX ? GRL_NONE : (unsigned)ml, tag));
-        } else if (tid == 64) {
+        if (tid == 64) {
             const int nevraw = scal[S_NEV];
             lst(mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
             scal[S_NEV] = 0; scal[S_NCAND] = 0;

@@ -401,6 +401,30 @@ def test_cli_results_csv(pkg, tmp_path):
     assert subprocess.run([pkg.CLI_PATH, "--csv", "x.csv"], capture_output=True).returncode == 255  # needs --program beta
 
 
+def test_cli_sharded_over_workers(pkg, tmp_path):
+    """`prach_sim --gpus N` / `--devices LIST`: host C forks one worker per device BEFORE any HIP call, deals the --times x sweep
+    grid by descending cost (glibc mode: whole seeds, the sweep of a seed is chained), every worker writes its own trials' files
+    and the parent merges the results through shared memory, printing in the reference's order.  Rehearsed on one GPU with two
+    workers on device 0: stdout, every file and results.csv equal the single-worker run, in both RNG modes."""
+    for rng in ("philox", "glibc"):
+        outs = {}
+        for tag, extra in (("one", []), ("two", ["--devices", "0,0"])):
+            d = tmp_path / f"{rng}_{tag}"
+            d.mkdir()
+            (d / "BasicBetaSimulationResults").mkdir()
+            p = subprocess.run([pkg.CLI_PATH, "--program", "beta", "--rng", rng, "--times", "4", "--sweep", "3000:9000:3000", "--out", str(d),
+                                "--logs", "1", "--csv", str(d / "results.csv")] + extra, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            files = {f.name: f.read_bytes() for f in sorted((d / "BasicBetaSimulationResults").iterdir())}
+            # (the sixth line of a Results.txt and the Latency line are wall clock)
+            files = {k: (b"\n".join(v.split(b"\n")[:5]) if k.endswith("_Results.txt") else v) for k, v in files.items()}
+            so = "\n".join(l for l in p.stdout.split("\n") if not l.startswith("Latency:"))
+            csv5 = [row.split(b",")[:5] for row in (d / "results.csv").read_bytes().split(b"\r\n")]
+            outs[tag] = (so, files, csv5)
+        assert outs["one"] == outs["two"], rng
+        assert len(outs["one"][1]) == 24 and len(split_stdout_blocks(outs["one"][0])) == 12
+
+
 def test_cli_results_csv_vs_reference_script(pkg, tmp_path):
     """The published experiment end to end on the GPU: `prach_sim --program beta -g 12 -t 100 --rng philox --csv` — 1000 trials
     in one call — against the results.csv the reference's own AveragePerformance.py wrote from the oracle's files for the
