@@ -444,7 +444,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || G > 64 || lgroups > 64 * NW) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
     unsigned long long deadmask = 0; // bit m: this wavefront's m-th group (local group w + NW * m) is finished for good
     int t5 = 0, tA = 0, slotA = 0;   // t mod 5, t mod accessTime, t / accessTime: kept incrementally
-    int acNext = sched[0];           // arrival table entry of the NEXT access slot, fetched one slot ahead
+    // arrival table entry of the NEXT access slot: fetched one slot ahead by a VECTOR load whose result is only made scalar
+    // (v_readfirstlane) when the slot begins — a scalar use right behind the load would park the wave for a full L2 round trip
+    // on the subframe's critical chain once per access slot
+    int acNextV = sched[0];
 #ifdef PRACH_STAMPS
     unsigned long long fstamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
     unsigned long long dstat[4] = {0, 0, 0, 0}; // thread 0: sum of queue lengths, round-1 bucket / event granules read again, refills
@@ -567,13 +570,17 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     int pendN = -1, pendFa = 0; // deferred calls of the previous subframe (pendN < 0: none)
 
     for (int t = 0; t < stop && status == PRACH_OK; t++) {
+        // (an opaque copy of the thread index: role predicates such as `tid < nP` are then recomputed where they are used — one v_cmp —
+        //  instead of being hoisted out of the step loop as 64-bit lane masks that live in, and spill from, scalar registers)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
         steps++;
         tlast = t;
         if (t5 == 0) grantCheck = 0; // Beta.c:112 (hard-coded 5)
         const int prevAC = activeCheck;
         if (tA == 0 && activeCheck != nUE) { // Beta.c:121-134: this access slot's arrivals (fetched a slot ago)
-            activeCheck = acNext;
-            acNext = sched[slotA + 1]; // (the table has maxTime / accessTime + 2 entries)
+            activeCheck = __builtin_amdgcn_readfirstlane(acNextV);
+            acNextV = sched[slotA + 1]; // (the table has maxTime / accessTime + 2 entries)
         }
         const int parity = t & 1;
         const unsigned tag = (unsigned)(t + 1);
@@ -617,8 +624,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         LSTAMP(2);
         // publish, first part: per bucket {histogram, lowest caller} — complete since S1; the header (event count) follows the leaver
         // filter.  Self-validating granules: the earlier they leave, the fewer of them the other workgroups have to read twice.
-        if (tid >= WG_THREADS - 64 && tid - (WG_THREADS - 64) < nP) { // (the last wavefront: the first ones run the leaver filter)
-            const int k = tid - (WG_THREADS - 64);
+        if (tl >= WG_THREADS - 64 && tl - (WG_THREADS - 64) < nP) { // (the last wavefront: the first ones run the leaver filter)
+            const int k = tl - (WG_THREADS - 64);
             const int ml = min(LI(lo::PAR + pc + lo::P_MLOC)[k], LI(lo::PAR + pc + lo::P_MLOCS)[k]);
             lst(mygr + 1 + k, lmk((unsigned)LI(lo::PAR + pc + lo::P_HIST)[k], ml == INT_MAX ? GRL_NONE : (unsigned)ml, tag));
         }
@@ -627,20 +634,20 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         {
             const int ncand = scal[S_NCAND];
             const int *const mloc = LI(lo::PAR + pc + lo::P_MLOC), *const mlocs = LI(lo::PAR + pc + lo::P_MLOCS);
-            for (int k = tid; k < ncand; k += WG_THREADS) {
+            for (int k = tl; k < ncand; k += WG_THREADS) {
                 const int2 c = LI2(lo::LCAND)[k];
                 if (c.x < min(mloc[c.y], mlocs[c.y])) {
                     const int es = atomicAdd(&scal[S_NEV], 1);
                     if (es < CLUSTER_EVW) lst(mbev + es, lmk((unsigned)c.x, (unsigned)(EVL_LEAVER | (c.y << 4)), tag));
                 }
             }
-            if (tid == 64) { scal[S_NS] = 0; scal[S_NRC] = 0; scal[S_NRJ] = 0; scal[S_QN] = 0; } // (the queue has been consumed)
+            if (tl == 64) { scal[S_NS] = 0; scal[S_NRC] = 0; scal[S_NRJ] = 0; scal[S_QN] = 0; } // (the queue has been consumed)
         }
         LSTAMP(3); // leaver filter
         __syncthreads(); // S2
         LSTAMP(4);
         // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
-        if (tid == 64) {
+        if (tl == 64) {
             const int nevraw = scal[S_NEV];
             lst(mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
             scal[S_NEV] = 0; scal[S_NCAND] = 0;
@@ -662,13 +669,13 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         if (ahead) {
             // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the pass of
             // subframe t left them
-            const int acN = (tA + 1 == aT && activeCheck != nUE) ? acNext : activeCheck;
+            const int acN = (tA + 1 == aT && activeCheck != nUE) ? __builtin_amdgcn_readfirstlane(acNextV) : activeCheck;
             phase_a(true, t + 1, activeCheck, acN, pn);
         }
         { // refill: the next two draws of every UE that drew in this subframe's phase B (off the chain: the exchange is in flight)
             const int nrq = min(scal[S_NRQ], LRQ);
             LSTAT(3, scal[S_NRQ]);
-            for (int k = tid; k < nrq; k += WG_THREADS) {
+            for (int k = tl; k < nrq; k += WG_THREADS) {
                 const int sl = LI(lo::RQ)[k];
                 const int i = l_idx_of(K, sl);
                 const unsigned nd = lnd[sl] & ~ND_READY;
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     if (ml != GRL_NONE) atomicMin(&fcallA[r1p[u]], (int)ml);
                 }
             }
-            for (int k = tid + 3 * WG_THREADS; k < G * nP; k += WG_THREADS) { // (more than 3072 bucket granules)
+            for (int k = tl + 3 * WG_THREADS; k < G * nP; k += WG_THREADS) { // (more than 3072 bucket granules)
                 const int wg = k / nP, p = k - wg * nP;
                 const long long g_ = lwait(mbpar + (unsigned)wg * mbs + 1u + (unsigned)p, tag, smem);
                 const unsigned h = (unsigned)g_ & 0xFFFFFu, ml = (unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu;
@@ -721,13 +728,13 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         LSTAMP(7); // round-1 granules taken
         __syncthreads(); // S3: totals, lowest definite callers, event offsets (and the next subframe's phase A)
         LSTAMP(8);
-        if (tid < NPCL) { // this parity is used again in two subframes
-            LI(lo::PAR + pc + lo::P_HIST)[tid] = 0; LI(lo::PAR + pc + lo::P_MLOC)[tid] = INT_MAX;
-            LI(lo::PAR + pc + lo::P_MLOCS)[tid] = INT_MAX; LI(lo::PAR + pc + lo::P_CANDN)[tid] = 0;
+        if (tl < NPCL) { // this parity is used again in two subframes
+            LI(lo::PAR + pc + lo::P_HIST)[tl] = 0; LI(lo::PAR + pc + lo::P_MLOC)[tl] = INT_MAX;
+            LI(lo::PAR + pc + lo::P_MLOCS)[tl] = INT_MAX; LI(lo::PAR + pc + lo::P_CANDN)[tl] = 0;
             // the resolver tables of the subframe before (read by this subframe's pass and by its deferred calls, both done): next subframe's [A]
-            LI(lo::FCALL + fb)[tid] = INT_MAX; LI(lo::LCALL + fb)[tid] = -1; LI(lo::TOTAL + fb)[tid] = 0; LI(lo::NLV + fb)[tid] = 0; LI(lo::FIE + fb)[tid] = 0;
+            LI(lo::FCALL + fb)[tl] = INT_MAX; LI(lo::LCALL + fb)[tl] = -1; LI(lo::TOTAL + fb)[tl] = 0; LI(lo::NLV + fb)[tl] = 0; LI(lo::FIE + fb)[tl] = 0;
         }
-        if (tid == 64) scal[S_NRQ] = 0; // (the refill list has been consumed)
+        if (tl == 64) scal[S_NRQ] = 0; // (the refill list has been consumed)
         if (scal[S_STATUS] != PRACH_OK) { status = scal[S_STATUS]; time_exit = t; break; }
         const int N = scal[S_NTOT];
         if (scal[S_OVF] || N > LEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on the general kernels
@@ -749,7 +756,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 }
             }
             if (scal[S_NREM] > 0) {
-                for (int k = tid; k < N; k += WG_THREADS) {
+                for (int k = tl; k < N; k += WG_THREADS) {
                     int lo_ = 0, hi_ = G; // workgroup whose segment holds event k
                     while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (evoff[mid] <= k) lo_ = mid; else hi_ = mid; }
                     const int es = k - evoff[lo_];
@@ -769,10 +776,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         const int nrc = scal[S_NRC];
         if (nrc > 0) { // rare: reset cycles that may re-join — decided strictly in index order, then recount
             if (nrc > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
-            if (tid < 64) l_resolve_reset_candidates(smem, fa, nrc, nP);
-            else if (tid < 64 + NPCL) { LI(lo::NLV + fa)[tid - 64] = 0; LI(lo::FIE + fa)[tid - 64] = 0; }
+            if (tl < 64) l_resolve_reset_candidates(smem, fa, nrc, nP);
+            else if (tl < 64 + NPCL) { LI(lo::NLV + fa)[tl - 64] = 0; LI(lo::FIE + fa)[tl - 64] = 0; }
             __syncthreads();
-            for (int k = tid; k < N; k += WG_THREADS) {
+            for (int k = tl; k < N; k += WG_THREADS) {
                 const int2 e = gev[k];
                 const int type = e.y & 7, p = (e.y >> 4) & 0xff;
                 if (type == EVL_LEAVER) { if (e.x < fcallA[p]) atomicAdd(&LI(lo::NLV + fa)[p], 1); }
@@ -816,24 +823,24 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         auto mine = [&](const int my) { return ((unsigned)(my >> 6) % (unsigned)G) == (unsigned)b; };
         if (Gr > 0 && ns > 0 && ns <= 64) {
             // up to one wavefront of singleton callers: every lane ranks its own index against the others through v_readlane
-            if (tid < 64) {
+            if (tl < 64) {
                 const int nsu = __builtin_amdgcn_readfirstlane(ns);
-                const int my = tid < nsu ? LI(lo::SIDX)[tid] : INT_MAX;
+                const int my = tl < nsu ? LI(lo::SIDX)[tl] : INT_MAX;
                 int rank = 0;
                 for (int s_ = 0; s_ < nsu; s_++) rank += __builtin_amdgcn_readlane(my, s_) < my ? 1 : 0;
-                if (tid < nsu && rank < Gr && mine(my)) grant(my);
+                if (tl < nsu && rank < Gr && mine(my)) grant(my);
             }
         } else if (Gr > 0 && ns > 0) { // (most subframes of an overloaded 5 ms window have no grant left: nothing to select)
             // the Gr lowest-index singleton callers, in O(ns): counts per index bin, block-wide exclusive prefix, whole bins below the
             // crossing bin are granted, the crossing bin is ranked exactly
             int *const bins = LI(lo::BINS), *const sidx = LI(lo::SIDX), *const rcl = LI(lo::RCL), *const wtot = LI(lo::WTOT);
-            bins[tid] = 0;
-            if (tid == 0) scal[S_NCROSS] = 0;
+            bins[tl] = 0;
+            if (tl == 0) scal[S_NCROSS] = 0;
             __syncthreads();
-            for (int j = tid; j < ns; j += WG_THREADS) atomicAdd(&bins[sidx[j] >> binshift], 1);
+            for (int j = tl; j < ns; j += WG_THREADS) atomicAdd(&bins[sidx[j] >> binshift], 1);
             __syncthreads();
             {
-                const int c = bins[tid];
+                const int c = bins[tl];
                 int x = c;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
@@ -841,10 +848,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 __syncthreads();
                 int add = 0;
                 for (int k = 0; k < w; k++) add += wtot[k];
-                bins[tid] = x - c + add; // exclusive prefix
+                bins[tl] = x - c + add; // exclusive prefix
             }
             __syncthreads();
-            for (int j = tid; j < ns; j += WG_THREADS) {
+            for (int j = tl; j < ns; j += WG_THREADS) {
                 const int my = sidx[j];
                 const int bin = my >> binshift;
                 const int before = bins[bin];
@@ -856,8 +863,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             __syncthreads();
             const int ncross = scal[S_NCROSS];
             if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
-            if (tid < ncross) {
-                const int my = rcl[tid];
+            if (tl < ncross) {
+                const int my = rcl[tl];
                 int rank = bins[my >> binshift];
                 for (int m = 0; m < ncross; m++) rank += rcl[m] < my ? 1 : 0;
                 if (rank < Gr && mine(my)) grant(my);
