@@ -371,6 +371,15 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     K.rarlim = (unsigned)(K.maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
     K.fmP = make_fastmod(K.nP); K.fmB = make_fastmod(PD->backoff); K.fmA = make_fastmod(K.aT); K.fm5 = make_fastmod(5);
     K.ptc = (PRACH_G int *)PD->ptc; K.ftt = (PRACH_G int *)PD->ftt; K.stt = (PRACH_G int *)PD->stt; K.fcnt = (PRACH_G int *)PD->fcnt;
+    // The event body's constants (divisor magics, retransmission limits, the cold-field pointers) are needed in ONE phase of the
+    // subframe; as wave-uniform values they would sit in scalar registers across the whole step loop, where the budget of 102 is
+    // already spent — and get spilled and reloaded (v_readlane) on the critical chain.  Held in vector registers instead (the
+    // wavefront has ~25 to spare at 4 waves per SIMD) they cost nothing to use: a VALU operand either way.
+#define LK_TO_VGPR(x) asm volatile("" : "+v"(x))
+    LK_TO_VGPR(K.fmP.d); LK_TO_VGPR(K.fmP.M); LK_TO_VGPR(K.fmB.d); LK_TO_VGPR(K.fmB.M); LK_TO_VGPR(K.fm5.d); LK_TO_VGPR(K.fm5.M);
+    LK_TO_VGPR(K.maxMsg2); LK_TO_VGPR(K.seed_lo); LK_TO_VGPR(K.seed_hi);
+    LK_TO_VGPR(K.ptc); LK_TO_VGPR(K.ftt); LK_TO_VGPR(K.stt); LK_TO_VGPR(K.fcnt);
+#undef LK_TO_VGPR
     const int nUE = K.nUE, nP = K.nP, aT = K.aT;
     const int stop = PD->stop, nGrantUL = PD->nGrantUL, binshift = PD->binshift;
     const PRACH_G int *const sched = (const PRACH_G int *)PD->sched;
