@@ -278,8 +278,20 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.flags = c.flags;
         d.sector = L.sector ? reinterpret_cast<int *>(A + L.sector) : nullptr;
         int32_t *sched = reinterpret_cast<int32_t *>(H + L.sched);
-        for (size_t s = 0; s < L.sched_len; s++) sched[s] = c.nUE;
-        prach_arrival_schedule(&c, sched, (int)L.sched_len, &nAccess[k]);
+        // the arrival table depends on (nUE, traffic law, accessTime) only: a sweep x seeds batch has a handful of distinct ones
+        // (2000 pow() calls each) — copy the previous trial's table when its key is the same
+        int same = -1;
+        for (int q = k - 1; q >= 0 && q >= k - 16; q--) {
+            const prach_cfg &o = cfgs[idx[q]];
+            if (o.nUE == c.nUE && o.uniform == c.uniform && o.accessTime == c.accessTime && o.variant == c.variant) { same = q; break; }
+        }
+        if (same >= 0) {
+            std::memcpy(sched, H + LL.t[same].sched, 4 * L.sched_len);
+            nAccess[k] = nAccess[same];
+        } else {
+            for (size_t s = 0; s < L.sched_len; s++) sched[s] = c.nUE;
+            prach_arrival_schedule(&c, sched, (int)L.sched_len, &nAccess[k]);
+        }
         if (rng_mode == PRACH_RNG_GLIBC)
             // the reference's rand() stream window [stream_offset, +stream_len): the host only jumps ahead (31-word window
             // per chunk, cached matrix powers); the values themselves are generated on the device inside the timed region

@@ -11,7 +11,7 @@ torch.distributed.run, one rank per GPU (RCCL).  One JSON line on rank 0.
           state resident in LDS); `value` = updates / wall time of the K timed calls.
   N > 1   step = BASELINE configs[4]: the `--times T` x nUE sweep (10 points, 10k..100k) grid of the Beta.c
           program, dealt to the ranks by descending cost (dist.shard_trials: STRONG scaling, the total work
-          does not depend on N), each rank runs its shard in one call per 1024 trials, then ONE sum
+          does not depend on N), each rank runs its shard in ONE call (one launch), then ONE sum
           all-reduce of the int64 aggregate block (RCCL) and the gather of the per-trial rows to rank 0
           (results.csv needs them: AveragePerformance.py:10-24).  `value` = total updates / max over ranks
           of the step time, collective and gather INCLUDED.  The reference runs this grid serially
@@ -190,7 +190,7 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
     cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_BETA_C, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(args.times) for n in points]
     mine = distmod.shard_trials(cfgs, rank, world)
     my_cfgs = [cfgs[i] for i in mine]
-    CH = 1024  # trials per call (bounds the device arena: 1024 trials = 2.7 GB)
+    CH = 16384  # trials per call: the whole shard in one launch (10 000 trials of the sweep = 27 GB of the 288 GB; fewer launch tails)
 
     def step():
         t0 = time.perf_counter()
