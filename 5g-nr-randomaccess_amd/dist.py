@@ -48,7 +48,7 @@ def aggregate_rows(cfgs, results, points):
     agg = np.zeros((len(points), len(AGG_FIELDS)), dtype=np.int64)
     pos = {p: k for k, p in enumerate(points)}
     for c, r in zip(cfgs, results):
-        if r.status != 0:
+        if getattr(r, "status", 0) != 0:  # (a trial that did not return PRACH_OK must never be averaged in)
             raise RuntimeError(f"trial (seed {int(c.seed)}, nUE {int(c.nUE)}) returned status {r.status}: refusing to aggregate it")
         k = pos[int(c.nUE)]
         row = (1, r.nSuccessUE, r.preambleTxCount, r.sumTimer, r.collisionPreambles, r.totalPreambleTxop,
