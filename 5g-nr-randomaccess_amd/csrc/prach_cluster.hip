@@ -61,7 +61,7 @@ constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups): on
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 enum { C_NSUCC = 0, C_COLL, C_TXOP, C_CONTF, C_NS, C_NRC, C_NRJ, C_STATUS, C_NEV, C_NCAND, C_OVF, C_NSUCCTOT, C_NTOT,
-       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20, C_GTOT = 21, C_QN = 22, C_QEND = 23 };
+       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20, C_GTOT = 21, C_QN = 22, C_QEND = 23, C_VISITS = 24, C_EVENTS = 25 };
 
 struct CLds {
     int2 *gev;    // [EVCAPC] gathered events of all workgroups
@@ -696,6 +696,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
             }
         }
     };
+    int nvisit = 0;
     // two record slots, refilled alternately: the next group's record is in flight while one is worked on
     int j0 = next_live(w);
     int j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
@@ -707,16 +708,17 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         const int4 ra = r0;
         j0 = j1 >= 0 ? next_live(j1 + NW) : -1;
         r0 = fetch(j0);
-        phase_a(ja, ra);
+        phase_a(ja, ra); nvisit++;
         if (j1 < 0) break;
         const int jb = j1;
         const int4 rb = r1;
         j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
         r1 = fetch(j1);
-        phase_a(jb, rb);
+        phase_a(jb, rb); nvisit++;
         if (!hooked) { late_hook(); hooked = true; }
     }
     if (!hooked) late_hook();
+    if (lane == 0 && nvisit) atomicAdd(&L.scal[C_VISITS], nvisit); // (reported, never read by the simulation)
     if (!SPEC && __any((c_succ | c_contf) != 0)) { // (only the in-place overflow path counts here)
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
@@ -1020,7 +1022,10 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             }
         }
         for (int k = tid; k < nP; k += WG_THREADS) { fcallB[k] = INT_MAX; lcallB[k] = -1; L.total[k] = 0; L.nlv[k] = 0; L.fie[k] = 0; } // ready for the gathers
-        if (tid == 0) { L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP; } // (the queue has been consumed)
+        if (tid == 0) {
+            L.scal[C_EVENTS] += min(L.scal[C_QN], (REC == REC_L16 ? INT_MAX : L.scal[C_QEND])); // (reported, never read by the simulation)
+            L.scal[C_NS] = 0; L.scal[C_NRC] = 0; L.scal[C_NRJ] = 0; L.scal[C_QN] = 0; L.scal[C_QEND] = QCAP; // (the queue has been consumed)
+        }
         FSTAMP(3); // leaver filter + table reset
         __syncthreads(); // S2
         FSTAMP(4); // S2
@@ -1326,6 +1331,10 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
             o->totalPreambleTxop = L.scal[C_TXOP];
             o->activeCheck = activeCheck;
             o->steps = steps;
+        }
+        if (L.scal[C_VISITS] | L.scal[C_EVENTS]) { // own-traffic accounting of the compacted pass (< 2^31 per workgroup and trial)
+            gadd(&o->visits, (unsigned long long)(unsigned)L.scal[C_VISITS]);
+            gadd(&o->events, (unsigned long long)(unsigned)L.scal[C_EVENTS]);
         }
     }
 }

@@ -404,6 +404,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         r.sumTimer = dr.sumTimer;
         r.draws = dr.draws;
         r.steps = dr.steps;
+        e->last.group_visits += dr.visits;
+        e->last.event_ues += dr.events;
         if (c.variant == PRACH_VARIANT_NOMA_C && dr.nSuccess == c.nUE && dr.dbg[0] > 0) { // all UEs succeeded: NOMA.c:707-710 breaks there
             r.time_exit = (int32_t)dr.dbg[0] - 1;
             r.steps = dr.dbg[0];

@@ -49,8 +49,10 @@ constexpr unsigned LSPIN = 1u << 22;
 constexpr int EVL_CALLER = 1, EVL_RESETCAND = 2, EVL_RJOIN = 3, EVL_LEAVER = 4; // (= prach_cluster.hip's EVC_*)
 
 // scalars in LDS
-enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_STATUS, S_NEV, S_NCAND, S_OVF, S_NSUCCTOT, S_NTOT, S_PTC, S_FC, S_SUMT = 16,
-       S_ND = 18, S_NCROSS = 20, S_QN = 22, S_NRQ = 23, S_NREM = 24 };
+enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_NEV = 8, S_NCAND, S_NSUCCTOT = 11, S_PTC = 13, S_FC, S_SUMT = 16,
+       S_ND = 18, S_NCROSS = 20, S_QN = 22, S_NRQ = 23,
+       // what every thread needs behind S3, in ONE 16-byte LDS read: status, gathered events, overflow flag, events beyond round 1
+       S_STATUS = 28, S_NTOT = 29, S_OVF = 30, S_NREM = 31 };
 
 // ---- LDS layout: byte offsets, all compile-time -------------------------------------------------------------------
 namespace lo {
@@ -193,16 +195,7 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
             const int e2 = philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, (unsigned)K.variant);
             if (!rdy) { d1 = e1; d2 = e2; }
         }
-        if (need > 0) {
-            ndc = k + (unsigned)need; nd_dirty = true; rdy = false;
-            const unsigned long long rm = __ballot(true); // (only lanes with need > 0 are here)
-            int base = 0;
-            const int first = __builtin_ctzll(rm);
-            if (lane == first) base = atomicAdd(&LI(lo::SCAL)[S_NRQ], __popcll(rm));
-            base = __shfl(base, first);
-            const int rs = base + __popcll(rm & lanemask_lt(lane));
-            if (rs < LRQ) LI(lo::RQ)[rs] = slot;
-        }
+        if (need > 0) { ndc = k + (unsigned)need; nd_dirty = true; rdy = false; } // (its refill is listed below)
     }
 
     // ---- selectPreamble / requestResourceAllocation on own state ----
@@ -273,28 +266,32 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
     if (u.pend == PEND_STAY) { if (__atomic_load_n(&mloc[oldp], __ATOMIC_RELAXED) > i) atomicMin(&mloc[oldp], i); }
     if (evtype == EVL_CALLER) atomicMin(&mloc[evp], i);
     {
-        const unsigned long long em = __ballot(evtype != 0);
-        if (em) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&LI(lo::SCAL)[S_NEV], __popcll(em));
-            base = __shfl(base, 0);
+        // special events -> this workgroup's mailbox, early-leaver candidates and refills -> their lists: the three list positions are
+        // taken by lane 0 with three returning LDS atomics issued back to back — ONE wait instead of three dependent round trips
+        const unsigned long long em = __ballot(evtype != 0), cm = __ballot(eclass), rm = __ballot(need > 0);
+        if (em | cm | rm) {
+            int b_ev = 0, b_cd = 0, b_rq = 0;
+            if (lane == 0) {
+                if (em) b_ev = atomicAdd(&LI(lo::SCAL)[S_NEV], __popcll(em));
+                if (cm) b_cd = atomicAdd(&LI(lo::SCAL)[S_NCAND], __popcll(cm));
+                if (rm) b_rq = atomicAdd(&LI(lo::SCAL)[S_NRQ], __popcll(rm));
+            }
+            b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd); b_rq = __builtin_amdgcn_readfirstlane(b_rq);
             if (evtype != 0) {
-                const int es = base + __popcll(em & lanemask_lt(lane));
+                const int es = b_ev + __popcll(em & lanemask_lt(lane));
                 const int ispre = (evtype == EVL_CALLER) ? (member_pre && oldp == evp) : (evtype == EVL_RESETCAND ? (evp == evq) : 0);
                 const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
                 if (es < CLUSTER_EVW) lst(mbev + es, lmk((unsigned)i, (unsigned)info, tag));
             }
-        }
-        const unsigned long long cm = __ballot(eclass);
-        if (cm) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&LI(lo::SCAL)[S_NCAND], __popcll(cm));
-            base = __shfl(base, 0);
             if (eclass) {
-                const int cs = base + __popcll(cm & lanemask_lt(lane));
+                const int cs = b_cd + __popcll(cm & lanemask_lt(lane));
                 if (cs < LCC) LI2(lo::LCAND)[cs] = make_int2(i, oldp);
                 else LI(lo::SCAL)[S_STATUS] = PRACH_ERR_INTERNAL; // (engine: exact rerun on the general kernels)
                 atomicAdd(&candn[oldp], 1);
+            }
+            if (need > 0) {
+                const int rs = b_rq + __popcll(rm & lanemask_lt(lane));
+                if (rs < LRQ) LI(lo::RQ)[rs] = slot;
             }
         }
     }
@@ -607,11 +604,12 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         }
         { // ---- phase B: the queued UEs through the full body, 64 at a time ----
             int c_succ = 0, c_contf = 0;
+            const int sl_first = queue[w * 64 + lane]; // (read together with the queue length: one LDS round trip, not two)
             const int qn = scal[S_QN];
             LSTAT(0, qn);
             for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
                 const bool v = q0 + lane < qn;
-                const int sl = v ? queue[q0 + lane] : 0;
+                const int sl = v ? (q0 == w * 64 ? sl_first : queue[q0 + lane]) : 0;
                 const int i = l_idx_of(K, sl);
                 int4 r = make_int4(-1, 0, 0, 0);
                 unsigned ndc = 0;
@@ -744,9 +742,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             LI(lo::FCALL + fb)[tl] = INT_MAX; LI(lo::LCALL + fb)[tl] = -1; LI(lo::TOTAL + fb)[tl] = 0; LI(lo::NLV + fb)[tl] = 0; LI(lo::FIE + fb)[tl] = 0;
         }
         if (tl == 64) scal[S_NRQ] = 0; // (the refill list has been consumed)
-        if (scal[S_STATUS] != PRACH_OK) { status = scal[S_STATUS]; time_exit = t; break; }
-        const int N = scal[S_NTOT];
-        if (scal[S_OVF] || N > LEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on the general kernels
+        const int4 ctl = *reinterpret_cast<const int4 *>(&scal[S_STATUS]); // {status, gathered events, overflow, events beyond round 1}
+        if (ctl.x != PRACH_OK) { status = ctl.x; time_exit = t; break; }
+        const int N = ctl.y;
+        if (ctl.z || N > LEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on the general kernels
         // the event granules: the first LEPF of every mailbox came with round 1 (each by the thread that fetched it), classified
         // against the lowest definite callers; a mailbox with more has the rest read now (a second round trip, rare)
         {
@@ -764,7 +763,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     }
                 }
             }
-            if (scal[S_NREM] > 0) {
+            if (ctl.w > 0) {
                 for (int k = tl; k < N; k += WG_THREADS) {
                     int lo_ = 0, hi_ = G; // workgroup whose segment holds event k
                     while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (evoff[mid] <= k) lo_ = mid; else hi_ = mid; }

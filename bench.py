@@ -350,10 +350,17 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
                 for s in range(100) for n in range(10000, 100001, 10000)]
         rs, _ = eng.run_trials(cfgs)
         upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
-        kms = eng.timing().kernel_ms
+        tm3 = eng.timing()
+        kms = tm3.kernel_ms
+        # the kernel's OWN bytes: a group visit of phase A reads one 8-byte hot record per lane; a UE through the event body reads 8 + 4 + 4 B
+        # (record, timer base, draw index) and writes about as much, plus ~8 B of cold fields
+        own = tm3.group_visits * 64 * 8 + tm3.event_ues * 40
         extras["config3_sweep_x100_1000_trials"] = {
             "kernel_updates_per_s": upd / (kms * 1e-3), "kernel_ms": kms, "updates": upd,
             "algorithmic_GBps_32B_per_update": 32.0 * upd / (kms * 1e-3) / 1e9,
+            "own_traffic": {"group_visits": tm3.group_visits, "event_ues": tm3.event_ues, "own_bytes": own, "own_bytes_per_update": own / upd,
+                            "own_GBps": own / (kms * 1e-3) / 1e9, "frac_of_hbm_peak": own / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "counter_traffic": "profiles/: FETCH_SIZE x2 + WRITE_SIZE of the same launch (compare: bytes beyond own_bytes are waste)"},
             "note": "32 B per update are the algorithmic bytes of the reference's dense formulation; the kernel skips finished / not yet arrived groups, "
                     "reads 8 B per visited UE and does not rewrite a UE in steady contention, so this is NOT an HBM fraction: the counter traffic of "
                     "this launch (FETCH_SIZE / WRITE_SIZE, separate passes) is in profiles/",
