@@ -46,7 +46,7 @@ fa, _ = pmc("pmc_fetch"); wa, _ = pmc("pmc_write"); f3, _ = pmc("c3_fetch"); w3,
 pf, _ = pmc("probe_fetch"); pw, _ = pmc("probe_write")
 fetch = fa[(main["Name"], "FETCH_SIZE")]; write = wa[(main["Name"], "WRITE_SIZE")]
 fetch3 = f3[(c3["Name"], "FETCH_SIZE")]; write3 = w3[(c3["Name"], "WRITE_SIZE")]
-probe = {k[0].split("(")[0]: v for k, v in pf.items() if "read_kernel" in k[0]}
+probe = {k[0][:48]: v for k, v in pf.items() if "read_kernel" in k[0]}
 probe_w = [v for k, v in pw.items() if "write_kernel" in k[0]][0]
 corr = 1048576.0 / (sum(probe.values()) / len(probe))  # 1 GiB = 1 048 576 KB was read by every read_kernel
 hbm = (corr * fetch + write) * 1024.0
