@@ -104,8 +104,12 @@ __device__ __forceinline__ void dead_mark(const CLds &L, const int j, const int 
     if (G > 1) atomicOr(&L.dead[(j >> 5) & (DEADW - 1)], 1u << (j & 31));
     else atomicOr(&L.dead[(j % NW) * DEADWW + ((j / NW) >> 5)], 1u << ((j / NW) & 31));
 }
+// One workgroup per trial: a wavefront walks its own run of bitmap words forward, and only it ever writes them — so the word it
+// is in stays in a scalar register (DeadCache) and the LDS is read once per 32 groups, not once per group visit (a dependent LDS
+// round trip on the path of every one of the ~98 visits per wavefront and subframe at nUE = 100 000).
+struct DeadCache { int widx; unsigned word; };
 // next live local group >= j of wavefront j % NW whose global group (b + G * j) is below ngroups, or -1 (wave-uniform)
-__device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b, const int G, const int ngroups) {
+__device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b, const int G, const int ngroups, DeadCache &dc) {
     if (G > 1) {
         for (int jj = j;; jj += NW) {
             if (b + G * jj >= ngroups) return -1;
@@ -116,7 +120,8 @@ __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b
     const int w = j & (NW - 1);
     int m = j / NW;
     if (j >= ngroups) return -1; // (G == 1, b == 0: local group == global group)
-    unsigned word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]);
+    if ((m >> 5) != dc.widx) { dc.widx = m >> 5; dc.word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]); }
+    unsigned word = dc.word;
     if (!((word >> (m & 31)) & 1u)) return j; // the common case while a trial is busy: the very next group is live
     for (;;) { // skip finished groups a word at a time
         const unsigned live = ~word >> (m & 31); // bit k: group m + k is live (zeros shifted in from the top = "not in this word")
@@ -126,7 +131,8 @@ __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b
         }
         m = (m | 31) + 1;
         if (w + NW * m >= ngroups) return -1;
-        word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]);
+        dc.widx = m >> 5;
+        word = dc.word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]);
     }
 }
 
@@ -137,54 +143,63 @@ __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b
 // indices: sized by the launch) is addressed through a run-time base.
 constexpr int NPC = 256; // stride of the per-bucket tables (nPreamble <= 254)
 constexpr int LQCAP = CLUSTER_LQCAP; // LDS-resident clusters: event queue = at most every owned UE slot
-namespace lds_off {
-constexpr int GEV = 0;
-constexpr int SIDX = GEV + 8 * EVCAPC;
-constexpr int RCLIST = SIDX + 4 * SCAPC;
-constexpr int SCAL = RCLIST + 4 * RCCAP;
-constexpr int DEAD = SCAL + 4 * 64;
-constexpr int EVOFF = DEAD + 4 * DEADW;
-constexpr int BINS = EVOFF + 4 * (MAXG + 16);
-constexpr int WTOT = BINS + 4 * GBINS;
-constexpr int HIST = WTOT + 4 * NW;       // [2][NPC] by subframe parity, like the next three
-constexpr int MLOC = HIST + 4 * 2 * NPC;
-constexpr int MLOC_STAY = MLOC + 4 * 2 * NPC;
-constexpr int CAND_N = MLOC_STAY + 4 * 2 * NPC;
-constexpr int TOTAL = CAND_N + 4 * 2 * NPC;
-constexpr int FCALL = TOTAL + 4 * NPC;    // [2][NPC]
-constexpr int LCALL = FCALL + 4 * 2 * NPC; // [2][NPC]
-constexpr int NLV = LCALL + 4 * 2 * NPC;
-constexpr int FIE = NLV + 4 * NPC;
-constexpr int QUEUE = FIE + 4 * NPC;
-constexpr int TAIL_G = QUEUE + 4 * QCAP;  // global-record kernels: (glibc) gsum, gpre, gmask follow the QCAP-entry queue
-constexpr int LCAND = QUEUE + 4 * LQCAP;  // LDS-resident kernels: LQCAP-entry queue, candidate list, then the launch-sized tail
-constexpr int TAIL_L = LCAND + 8 * LCANDCAP;
-} // namespace lds_off
-static_assert(lds_off::SIDX % 16 == 0 && lds_off::TAIL_L % 16 == 0, "16-byte alignment of the event and record arrays");
+// Two layouts: the general one (bucket stride 256, QCAP-entry queue) and the SMALL one of the streaming regime (one workgroup per
+// trial, nPreamble <= 64: bucket stride 64, half the queue, half the gathered-event list) — 61 KB instead of 97 KB, so that TWO
+// 1024-thread workgroups (two independent trials) share a CU: 8 wavefronts per SIMD instead of 4.
+template <int NPC_, int QCAP_, int EVC_>
+struct LdsOff {
+    static constexpr int GEV = 0;
+    static constexpr int SIDX = GEV + 8 * EVC_;
+    static constexpr int RCLIST = SIDX + 4 * SCAPC;
+    static constexpr int SCAL = RCLIST + 4 * RCCAP;
+    static constexpr int DEAD = SCAL + 4 * 64;
+    static constexpr int EVOFF = DEAD + 4 * DEADW;
+    static constexpr int BINS = EVOFF + 4 * (MAXG + 16);
+    static constexpr int WTOT = BINS + 4 * GBINS;
+    static constexpr int HIST = WTOT + 4 * NW;       // [2][NPC] by subframe parity, like the next three
+    static constexpr int MLOC = HIST + 4 * 2 * NPC_;
+    static constexpr int MLOC_STAY = MLOC + 4 * 2 * NPC_;
+    static constexpr int CAND_N = MLOC_STAY + 4 * 2 * NPC_;
+    static constexpr int TOTAL = CAND_N + 4 * 2 * NPC_;
+    static constexpr int FCALL = TOTAL + 4 * NPC_;    // [2][NPC]
+    static constexpr int LCALL = FCALL + 4 * 2 * NPC_; // [2][NPC]
+    static constexpr int NLV = LCALL + 4 * 2 * NPC_;
+    static constexpr int FIE = NLV + 4 * NPC_;
+    static constexpr int QUEUE = FIE + 4 * NPC_;
+    static constexpr int TAIL_G = QUEUE + 4 * QCAP_;  // global-record kernels: (glibc) gsum, gpre, gmask follow the QCAP-entry queue
+    static constexpr int LCAND = QUEUE + 4 * LQCAP;  // LDS-resident kernels: LQCAP-entry queue, candidate list, then the launch-sized tail
+    static constexpr int TAIL_L = LCAND + 8 * LCANDCAP;
+    static_assert(SIDX % 16 == 0 && TAIL_L % 16 == 0, "16-byte alignment of the event and record arrays");
+};
+constexpr int NPC_S = 64, QCAP_S = QCAP < 4096 ? QCAP : 4096, EVC_S = 2048; // the small layout
+constexpr int NPC_G = NPC, QCAP_G = QCAP, EVCAPC_G = EVCAPC; // (the kernel shadows the three names with its layout's values)
+using lds_off = LdsOff<NPC, QCAP, EVCAPC>;
+using lds_off_s = LdsOff<NPC_S, QCAP_S, EVC_S>;
+static_assert(lds_off_s::TAIL_G <= 80 * 1024, "two workgroups of the small layout per CU");
 
+template <class O>
 __device__ __forceinline__ CLds ccarve(char *smem, bool glibc, int lslots) {
-    using namespace lds_off;
     CLds L;
-    L.gev = reinterpret_cast<int2 *>(smem + GEV);
-    L.sidx = reinterpret_cast<int *>(smem + SIDX);
-    L.rclist = reinterpret_cast<int *>(smem + RCLIST);
-    L.scal = reinterpret_cast<int *>(smem + SCAL);
-    L.dead = reinterpret_cast<unsigned *>(smem + DEAD);
-    L.evoff = reinterpret_cast<int *>(smem + EVOFF);
-    L.bins = reinterpret_cast<int *>(smem + BINS);
-    L.wtot = reinterpret_cast<int *>(smem + WTOT);
-    L.hist = reinterpret_cast<int *>(smem + HIST); L.mloc = reinterpret_cast<int *>(smem + MLOC);
-    L.mloc_stay = reinterpret_cast<int *>(smem + MLOC_STAY); L.cand_n = reinterpret_cast<int *>(smem + CAND_N);
-    L.total = reinterpret_cast<int *>(smem + TOTAL); L.fcall = reinterpret_cast<int *>(smem + FCALL);
-    L.lcall = reinterpret_cast<int *>(smem + LCALL); L.nlv = reinterpret_cast<int *>(smem + NLV); L.fie = reinterpret_cast<int *>(smem + FIE);
-    L.queue = reinterpret_cast<int *>(smem + QUEUE);
-    L.gsum = reinterpret_cast<int *>(smem + TAIL_G); L.gpre = L.gsum + GSCAP; L.gmask = reinterpret_cast<unsigned *>(L.gsum + 2 * GSCAP); // only touched in glibc mode
+    L.gev = reinterpret_cast<int2 *>(smem + O::GEV);
+    L.sidx = reinterpret_cast<int *>(smem + O::SIDX);
+    L.rclist = reinterpret_cast<int *>(smem + O::RCLIST);
+    L.scal = reinterpret_cast<int *>(smem + O::SCAL);
+    L.dead = reinterpret_cast<unsigned *>(smem + O::DEAD);
+    L.evoff = reinterpret_cast<int *>(smem + O::EVOFF);
+    L.bins = reinterpret_cast<int *>(smem + O::BINS);
+    L.wtot = reinterpret_cast<int *>(smem + O::WTOT);
+    L.hist = reinterpret_cast<int *>(smem + O::HIST); L.mloc = reinterpret_cast<int *>(smem + O::MLOC);
+    L.mloc_stay = reinterpret_cast<int *>(smem + O::MLOC_STAY); L.cand_n = reinterpret_cast<int *>(smem + O::CAND_N);
+    L.total = reinterpret_cast<int *>(smem + O::TOTAL); L.fcall = reinterpret_cast<int *>(smem + O::FCALL);
+    L.lcall = reinterpret_cast<int *>(smem + O::LCALL); L.nlv = reinterpret_cast<int *>(smem + O::NLV); L.fie = reinterpret_cast<int *>(smem + O::FIE);
+    L.queue = reinterpret_cast<int *>(smem + O::QUEUE);
+    L.gsum = reinterpret_cast<int *>(smem + O::TAIL_G); L.gpre = L.gsum + GSCAP; L.gmask = reinterpret_cast<unsigned *>(L.gsum + 2 * GSCAP); // only touched in glibc mode
     (void)glibc;
     L.lrec = nullptr; L.lnd = nullptr; L.lcand = nullptr;
     if (lslots > 0) { // (never together with glibc mode)
-        L.lcand = reinterpret_cast<int2 *>(smem + LCAND);
-        L.lrec = reinterpret_cast<int4 *>(smem + TAIL_L);
-        L.lnd = reinterpret_cast<unsigned *>(smem + TAIL_L + 16 * lslots);
+        L.lcand = reinterpret_cast<int2 *>(smem + O::LCAND);
+        L.lrec = reinterpret_cast<int4 *>(smem + O::TAIL_L);
+        L.lnd = reinterpret_cast<unsigned *>(smem + O::TAIL_L + 16 * lslots);
     }
     return L;
 }
@@ -227,9 +242,11 @@ __device__ __forceinline__ long long wait_granule(const PRACH_G long long *p, un
 //            whole trial (49 groups x 64 UEs x 20 bytes = 63 KB at nUE = 100 000, G = 32): the pass, the event body and the grant
 //            never touch L2 for a record; global memory only sees the cold per-UE fields and the final state
 constexpr int REC_G16 = 0, REC_H8 = 1, REC_L16 = 2;
-template <int REC_>
+template <int REC_, bool SMALL_ = false>
 struct CtxT {
     static constexpr int REC = REC_;
+    static constexpr int QCAPX = SMALL_ ? QCAP_S : QCAP;     // event queue entries
+    static constexpr int EVCX = SMALL_ ? EVC_S : EVCAPC;      // gathered events held in LDS
     static constexpr bool H8 = REC_ == REC_H8;   // 8 + 4 byte hot record (one workgroup per trial, streaming)
     static constexpr bool LREC = REC_ == REC_L16; // LDS-resident records
     int b, G, evw, mbstride;
@@ -518,7 +535,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
                 const int slot = base + __popcll(em & lanemask_lt(lane));
                 const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
                 const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
-                if (C.G == 1) { if (slot < EVCAPC) L.gev[slot] = make_int2(i, info); }
+                if (C.G == 1) { if (slot < CX::EVCX) L.gev[slot] = make_int2(i, info); }
                 else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)i, (unsigned)info, tag));
             }
         }
@@ -553,7 +570,8 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
 
     // software pipeline: the next live groups' records (and Philox draw indices) are in flight while the
     // current group is processed
-    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups); }; // wave-uniform
+    DeadCache dc{-1, 0u};
+    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups, dc); }; // wave-uniform
     // two groups ahead (slots A, B; three ahead measured slower).  The load itself is unconditional (record 0 is always
     // mapped) and the "nothing there" case is applied where the record is consumed: a conditional load would have to be
     // waited for on the spot to merge it with the default value, which serialises the prefetches.
@@ -623,7 +641,8 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     const int ngroups = (activeCheck + 63) >> 6;
     const int nUE = P.nUE, maxRar = P.maxRarWindow;
     int c_succ = 0, c_contf = 0;
-    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups); }; // wave-uniform
+    DeadCache dc{-1, 0u};
+    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups, dc); }; // wave-uniform
     // The prefetch is an unconditional load of an in-range record (lanes past the arrived UEs re-read the last one and
     // ignore it): nothing has to be merged with a default value, so nothing is waited for before the record is used.
     const unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
@@ -658,7 +677,10 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         const bool heavy = !lightc && !quiet;
         if (!__any(lightc || heavy)) {
             // nothing happens in this group; retire it for good once every UE in it has finished
-            if (__all(done) && lane == 0) dead_mark(L, j, C.G);
+            if (__all(done)) {
+                if (lane == 0) dead_mark(L, j, C.G);
+                if (C.G == 1 && ((j / NW) >> 5) == dc.widx) dc.word |= 1u << ((j / NW) & 31); // (the register copy of this wavefront's word)
+            }
             return;
         }
         if (lightc) { // Beta.c:245 + the txTime++ of Beta.c:346,358
@@ -683,7 +705,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_QN], n);
             base = __shfl(base, 0);
-            if (CX::LREC || base + n <= QCAP) { // (LDS-resident: the queue holds slots and has room for every owned UE)
+            if (CX::LREC || base + n <= CX::QCAPX) { // (LDS-resident: the queue holds slots and has room for every owned UE)
                 if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = CX::LREC ? j * 64 + lane : i;
             } else if (SPEC) { // cannot happen: the kernel runs ahead only if every owned UE fits the queue
                 if (lane == 0) L.scal[C_STATUS] = PRACH_ERR_INTERNAL;
@@ -831,21 +853,27 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fca
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
-template <bool GLIBC, int REC>
-__global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots) {
+template <bool GLIBC, int REC, bool SMALL>
+__global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(const TrialDev *__restrict__ params, const int Garg, const int lslots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPC = SMALL ? NPC_S : NPC_G, QCAP = SMALL ? QCAP_S : QCAP_G, EVCAPC = SMALL ? EVC_S : EVCAPC_G;
+    using LO = LdsOff<NPC, QCAP, EVCAPC>;
+    // the 8 + 4 byte record form is only ever launched with ONE workgroup per trial (the streaming regime): there the cluster size is a
+    // compile-time 1 and every exchange / mailbox / pipeline path of this kernel is dead code the compiler drops (half the code, fewer
+    // live scalars in the pass)
+    const int G = REC == REC_H8 ? 1 : Garg;
     // the workgroups of a cluster are CONSECUTIVE blocks: in-order dispatch completes whole clusters even when not every
     // block of the grid is resident at once (the engine keeps G x trials within the occupancy query's answer anyway)
     const int T = blockIdx.x / G, b = blockIdx.x % G;
     const TrialG P(params[T]);
-    const CLds L = ccarve(smem, GLIBC, REC == REC_L16 ? lslots : 0);
+    const CLds L = ccarve<LO>(smem, GLIBC, REC == REC_L16 ? lslots : 0);
     const int tid = threadIdx.x;
     const int nUE = P.nUE, nP = P.nP, aT = P.aT;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
 
     FastMods FM;
     FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
-    CtxT<REC> C;
+    CtxT<REC, SMALL> C;
     C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox;
     C.fmG = make_fastmod(G); C.lrec = L.lrec; C.lnd = L.lnd; C.lcand = L.lcand;
     C.status_word = &L.scal[C_STATUS];
@@ -1339,23 +1367,28 @@ __global__ __launch_bounds__(WG_THREADS) void cluster_kernel(const TrialDev *__r
     }
 }
 
-size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots) {
-    (void)nP; // the per-bucket tables have the fixed stride NPC
+// small: the streaming layout (one workgroup per trial, Philox, nPreamble <= 64): two workgroups per CU
+size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small) {
+    (void)nP; // the per-bucket tables have a fixed stride
+    if (small) return (size_t)lds_off_s::TAIL_G;
     if (lslots > 0) return (size_t)lds_off::TAIL_L + (size_t)lslots * 20;
     return (size_t)lds_off::TAIL_G + (glibc ? sizeof(int) * 4 * GSCAP : 0);
 }
+int cluster_small_max_preambles() { return NPC_S; }
 
 using cluster_kernel_t = void (*)(const TrialDev *, int, int);
 // rec_mode: REC_G16 / REC_H8 (one workgroup per trial: the streaming regime) / REC_L16 (clusters, Philox: LDS-resident records)
-static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode) {
-    if (rng_mode == PRACH_RNG_GLIBC) return rec_mode == REC_H8 ? cluster_kernel<true, REC_H8> : cluster_kernel<true, REC_G16>;
-    return rec_mode == REC_L16 ? cluster_kernel<false, REC_L16> : (rec_mode == REC_H8 ? cluster_kernel<false, REC_H8> : cluster_kernel<false, REC_G16>);
+static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode, bool small) {
+    if (rng_mode == PRACH_RNG_GLIBC) return rec_mode == REC_H8 ? cluster_kernel<true, REC_H8, false> : cluster_kernel<true, REC_G16, false>;
+    if (small && rec_mode == REC_H8) return cluster_kernel<false, REC_H8, true>;
+    return rec_mode == REC_L16 ? cluster_kernel<false, REC_L16, false> : (rec_mode == REC_H8 ? cluster_kernel<false, REC_H8, false> : cluster_kernel<false, REC_G16, false>);
 }
 
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, hipStream_t stream) {
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, hipStream_t stream) {
     if (rec_mode != REC_L16) lslots = 0;
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots);
-    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode);
+    small = small && rec_mode == REC_H8 && rng_mode != PRACH_RNG_GLIBC;
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, small);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode, small);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(fn, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, lslots);
@@ -1365,8 +1398,8 @@ hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int
 // workgroups of this kernel (with its dynamic LDS) the runtime admits per CU: what a cooperative launch would be checked against
 int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots) {
     if (rec_mode != REC_L16) lslots = 0;
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots);
-    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode);
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, false);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode, false);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;

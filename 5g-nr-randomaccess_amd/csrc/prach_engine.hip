@@ -49,6 +49,7 @@ struct prach_engine {
 #else
     int64_t opt_lds_records = 1;   // 0: clusters keep their UE records in global memory (diagnostic)
 #endif
+    int64_t opt_two_per_cu = 0;    // 1: the streaming regime on the small LDS layout, two 1024-thread workgroups per CU (measured slower: DESIGN.md section 4)
     int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
     int num_cus = 256;
 };
@@ -367,7 +368,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         const int rec_mode = use_fast_kernel(e, lslots, maxP) ? CLUSTER_REC_LFAST : (lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16));
         e->last.rec_mode = rec_mode;
         if (rec_mode == CLUSTER_REC_LFAST) HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, e->stream));
-        else HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, e->stream));
+        else {
+            // the streaming layout (two 1024-thread workgroups = two independent trials per CU): one workgroup per trial, Philox, <= 64 preambles
+            const int small = rec_mode == CLUSTER_REC_H8 && rng_mode == PRACH_RNG_PHILOX && maxP <= cluster_small_max_preambles() && e->opt_two_per_cu;
+            HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, small, e->stream));
+        }
     }
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(A), m, rng_mode, maxP, e->stream));
     HIPCHK(hipEventRecord(e->ev1, e->stream));
@@ -618,6 +623,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "host_threads") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_host_threads = value; return PRACH_OK; }
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "two_per_cu") == 0) { e->opt_two_per_cu = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }
 

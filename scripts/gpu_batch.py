@@ -18,3 +18,8 @@ upd = sum(c.nUE * r.steps for c, r in zip(cfgs, res))
 print(f"trials={len(cfgs)} variant={variant} G={G} launches={tm.launches} wgs={tm.workgroups} kernel={tm.kernel_ms:.1f}ms wall={wall:.2f}s updates={upd:.3e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} algoGB/s={32*upd/(tm.kernel_ms*1e-3)/1e9:.0f} bad={sum(r.status!=0 for r in res)}")
 own = tm.group_visits * 64 * 8 + tm.event_ues * 40
 print(f"own traffic: {tm.group_visits:.3e} group visits, {tm.event_ues:.3e} event UEs -> {own/1e9:.1f} GB = {own/upd:.2f} B/update = {own/(tm.kernel_ms*1e-3)/1e12:.2f} TB/s")
+if len(sys.argv) > 4:  # compare with the general layout (one workgroup per CU)
+    eng.set("two_per_cu", 0)
+    res, _ = eng.run_trials(cfgs)
+    tm = eng.timing()
+    print(f"two_per_cu=0: kernel={tm.kernel_ms:.1f}ms kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e}")
