@@ -70,13 +70,50 @@ def allreduce_aggregates(agg: np.ndarray, device=None):
     return t.cpu().numpy()
 
 
-def gather_trial_rows(rows, dst: int = 0):
-    """Per-trial rows (small python tuples) gathered to `dst` in rank order; None elsewhere."""
+ROW_BYTES = 120  # a row = (trial index, short text): index in 8 bytes + up to 112 bytes of text
+
+
+def gather_trial_rows(rows, dst: int = 0, device=None):
+    """Per-trial rows [(trial index, text or int), ...] gathered to `dst` in rank order; None elsewhere.
+    Carried by ONE tensor all-gather of fixed-size byte records (a native collective of RCCL and gloo alike — no pickled-object
+    collective on the critical path of the multi-GPU bench); every rank pads to the largest shard."""
+    import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return list(rows)
-    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(list(rows), out, dst=dst)
-    if out is None:
+    world = dist.get_world_size()
+    n = torch.tensor([len(rows)], dtype=torch.int64)
+    if device is not None:
+        n = n.to(device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    nmax = max(int(c.item()) for c in counts)
+    buf = np.zeros((max(nmax, 1), ROW_BYTES), dtype=np.uint8)
+    kinds = set()
+    for k, (idx, val) in enumerate(rows):
+        if isinstance(val, (int, np.integer)):
+            payload, kind = str(int(val)).encode(), b"i"
+        else:
+            payload, kind = (val if isinstance(val, bytes) else str(val).encode()), b"s"
+        if len(payload) > ROW_BYTES - 10:
+            raise ValueError(f"row text of {len(payload)} bytes does not fit the {ROW_BYTES}-byte record")
+        kinds.add(kind)
+        rec = int(idx).to_bytes(8, "little") + kind + bytes([len(payload)]) + payload
+        buf[k, :len(rec)] = np.frombuffer(rec, dtype=np.uint8)
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    if dist.get_rank() != dst:
         return None
-    return [r for part in out for r in part]
+    out = []
+    for r in range(world):
+        a = parts[r].cpu().numpy()
+        for k in range(int(counts[r].item())):
+            raw = a[k].tobytes()
+            idx = int.from_bytes(raw[:8], "little")
+            ln = raw[9]
+            payload = raw[10:10 + ln]
+            out.append((idx, int(payload) if raw[8:9] == b"i" else payload.decode()))
+    return out

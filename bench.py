@@ -203,7 +203,7 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
         agg = distmod.aggregate_rows(my_cfgs, res, points)  # raises if a trial did not return PRACH_OK
         tot = distmod.allreduce_aggregates(agg, device=cdev if (dist is not None and args.backend == "nccl") else None)
         rows = [(i, pkg.format_results(cfgs[i], r, 0.0).decode()) for i, r in zip(mine, res)]
-        allrows = distmod.gather_trial_rows(rows, dst=0)
+        allrows = distmod.gather_trial_rows(rows, dst=0, device=cdev if (dist is not None and args.backend == "nccl") else None)
         return tot, allrows, t_sim, kms, time.perf_counter() - t0
 
     for _ in range(args.warmup):
