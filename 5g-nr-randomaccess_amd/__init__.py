@@ -117,7 +117,7 @@ EXPORTS = ("prach_engine_create", "prach_engine_destroy", "prach_engine_set", "p
            "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_arrival_schedule", "prach_glibc_stream",
            "prach_strerror", "prach_format_logs", "prach_format_results", "prach_format_stdout",
            "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line",
-           "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream", "prach_noma_activation_range")
+           "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream", "prach_noma_activation_range", "prach_noma_activation_stream")
 
 
 def make_cfg(nUE, variant=VARIANT_BETA_C, uniform=0, rng_mode=RNG_GLIBC, seed=0, stream_offset=0, **kw) -> PrachCfg:

@@ -9,7 +9,8 @@
  *
  * `--program noma` runs NOMA.c's loop instead (NOMA.c:644-717: 10 seeds by default, one result line per
  * (seed, nUE) on stdout and appended to TestResults/Sector_{nUE}_Result.txt, "Done" per seed); that
- * variant draws from Philox (the reference's rand() stream position is data dependent there).
+ * variant draws from Philox by default; `--rng glibc` runs it in the reference's own rand() stream (the arrivals of every access
+ * slot are then activated on the host between device steps: prach_noma_glibc.hip), chained over the sweep of a seed like NOMA.c:644-647.
  *
  * Extensions (not in the reference): --program beta|withnoma|noma, --rng glibc|philox, --nue N,
  * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N, --csv FILE (--program beta: the results.csv of
@@ -142,8 +143,10 @@ static int run_worker(int device, const prach_cfg *cfgs, const int *idx, int m, 
                 offset[s_] += r[s_].draws;
                 res[idx[s_ * npts + k]] = r[s_];
                 lat_out[idx[s_ * npts + k]] = lat;
-                rc = prach_write_trial_files(&c[s_], &r[s_], want_logs ? logs[s_] : NULL, lat, outdir);
-                if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+                if (c[s_].variant != PRACH_VARIANT_NOMA_C) { /* (NOMA.c's lines are printed and appended by the parent) */
+                    rc = prach_write_trial_files(&c[s_], &r[s_], want_logs ? logs[s_] : NULL, lat, outdir);
+                    if (rc != PRACH_OK) { fprintf(stderr, "prach_sim: %s\n", prach_strerror(rc)); return 2; }
+                }
                 if (want_logs) { free(logs[s_]); logs[s_] = NULL; }
             }
         }
@@ -155,7 +158,7 @@ static int run_worker(int device, const prach_cfg *cfgs, const int *idx, int m, 
 }
 
 int main(int argc, char *argv[]) {
-    int randomMax = 1, variant = PRACH_VARIANT_WITHNOMA_C, rng = PRACH_RNG_GLIBC, device = 0, want_logs = 1, gpus = 1;
+    int randomMax = 1, variant = PRACH_VARIANT_WITHNOMA_C, rng = PRACH_RNG_GLIBC, device = 0, want_logs = 1, gpus = 1, rng_given = 0;
     int sweep_lo = 10000, sweep_hi = 100000, sweep_step = 10000; /* WithNOMA:221 */
     const char *outdir = ".", *csv_path = NULL, *devlist = NULL;
     int devs[64];
@@ -208,6 +211,7 @@ int main(int argc, char *argv[]) {
             /* handled above */
         } else if (strcmp(a, "--rng") == 0) {
             rng = strcmp(v, "philox") == 0 ? PRACH_RNG_PHILOX : PRACH_RNG_GLIBC;
+            rng_given = 1;
         } else if (strcmp(a, "--nue") == 0) {
             if (atoi(v) < 1) die("Number of UEs must be greater than zero.");
             sweep_lo = sweep_hi = atoi(v); sweep_step = 1;
@@ -237,7 +241,7 @@ int main(int argc, char *argv[]) {
     }
     base.rng_mode = rng;
     if (csv_path && variant != PRACH_VARIANT_BETA_C) die("--csv needs --program beta (AveragePerformance.py reads its six-number Results.txt)");
-    if (variant == PRACH_VARIANT_NOMA_C) { base.rng_mode = rng = PRACH_RNG_PHILOX; want_logs = 0; }
+    if (variant == PRACH_VARIANT_NOMA_C) { want_logs = 0; if (!rng_given) rng = PRACH_RNG_PHILOX; base.rng_mode = rng; } /* --rng glibc: NOMA.c's own rand() stream */
 
     /* the grid: trial (seed s, sweep point k) = cfgs[s * npts + k], the reference's loop order (WithNOMA:216-221 / NOMA.c:644-647) */
     const int npts = (sweep_hi - sweep_lo) / sweep_step + 1;

@@ -110,5 +110,8 @@ constexpr int CLUSTER_MAX_G = 64;
 size_t noma_kernel_lds_bytes(int nP);
 hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
 int noma_kernel_blocks_per_cu(int maxP);
+// NOMA_C in the reference's own rand() stream (prach_noma_glibc.hip): one trial, host-activated arrivals + one device step per access slot
+int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *hstream, unsigned long long len, prach_result *res, prach_ue_log *logs,
+                         double *kernel_ms);
 
 } // namespace prach

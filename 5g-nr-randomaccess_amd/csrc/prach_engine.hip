@@ -463,17 +463,31 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
     for (int k = 0; k < n; k++) {
         int v = prach_cfg_validate(&cfgs[k]);
         if (v != PRACH_OK) return v;
-        if (cfgs[k].variant == PRACH_VARIANT_NOMA_C && (cfgs[k].rng_mode != PRACH_RNG_PHILOX || cfgs[k].nPreamble > 64 || cfgs[k].uniform))
-            return PRACH_ERR_UNSUPPORTED; // the rejection loops of activeUE make the glibc stream position data dependent
+        if (cfgs[k].variant == PRACH_VARIANT_NOMA_C && (cfgs[k].nPreamble > 64 || cfgs[k].uniform)) return PRACH_ERR_UNSUPPORTED;
     }
     HIPCHK(hipSetDevice(e->device));
     auto t0 = std::chrono::steady_clock::now();
     e->last = prach_timing{};
     double kernel_ms = 0, upload_ms = 0;
-    { // NOMA.c variant: its own kernel, G workgroups per trial like the production kernel
+    // NOMA.c in the reference's OWN rand() stream: activeUE's rejection loops make every stream position data dependent and its libm
+    // calls must be the reference's, so the arrivals are activated on the host between device steps (prach_noma_glibc.hip): one trial
+    // at a time, one launch per access slot — the bit-exact-vs-the-reference's-files mode, not the throughput mode
+    for (int k = 0; k < n; k++) {
+        if (cfgs[k].variant != PRACH_VARIANT_NOMA_C || cfgs[k].rng_mode != PRACH_RNG_GLIBC) continue;
+        int rc = PRACH_ERR_STREAM;
+        for (int attempt = 0; attempt < 6 && rc == PRACH_ERR_STREAM; attempt++) {
+            const unsigned long long len = ((unsigned long long)cfgs[k].nUE * 48ull + (1ull << 18)) << (2 * attempt);
+            std::vector<int32_t> hs((size_t)len);
+            prach_glibc_stream((uint32_t)cfgs[k].seed, cfgs[k].stream_offset, len, hs.data());
+            rc = run_noma_glibc_trial(e->stream, cfgs[k], hs.data(), len, &results[k], ue_logs ? ue_logs[k] : nullptr, &kernel_ms);
+            e->last.launches++;
+        }
+        if (rc != PRACH_OK) return rc;
+    }
+    { // NOMA.c variant (Philox): its own kernel, G workgroups per trial like the production kernel
         std::vector<int> idx;
         for (int k = 0; k < n; k++)
-            if (cfgs[k].variant == PRACH_VARIANT_NOMA_C) idx.push_back(k);
+            if (cfgs[k].variant == PRACH_VARIANT_NOMA_C && cfgs[k].rng_mode == PRACH_RNG_PHILOX) idx.push_back(k);
         if (!idx.empty()) {
             int minGroups = INT_MAX, maxP = 1;
             bool small = true;

@@ -65,7 +65,7 @@ const char *prach_strerror(int s) {
     switch (s) {
     case PRACH_OK: return "ok";
     case PRACH_ERR_ARG: return "invalid argument";
-    case PRACH_ERR_UNSUPPORTED: return "parameter outside the supported range (nPreamble<=254, maxRarWindow<=255, maxMsg2TxCount<=255, nUE<=2^24; NOMA_C: nPreamble<=64, Philox draws, Beta arrivals)";
+    case PRACH_ERR_UNSUPPORTED: return "parameter outside the supported range (nPreamble<=254, maxRarWindow<=255, maxMsg2TxCount<=255, nUE<=2^24; NOMA_C: nPreamble<=64, Beta arrivals)";
     case PRACH_ERR_DEVICE: return "HIP device/runtime error (an MI355X/gfx950 device is required; there is no CPU fallback)";
     case PRACH_ERR_STREAM: return "glibc draw stream exhausted";
     case PRACH_ERR_INTERNAL: return "device-side consistency check failed";
@@ -191,6 +191,50 @@ int prach_noma_activation_range(const prach_cfg *c, int lo, int hi, int32_t *pre
         lgain[i] = log(ch_g);
         ndraws[i] = k;
     }
+    return PRACH_OK;
+}
+
+/* activeUE (NOMA.c:131-192) for ONE UE in the reference's own rand() stream: the draws are stream[*pos], stream[*pos + 1], ... in the
+ * order the reference consumes them (preamble, angle, the radius rejection loop, the Rayleigh-gain rejection loop); *pos advances by the
+ * number consumed.  Used by the glibc-mode NOMA path (prach_noma_glibc.hip), where the host activates the arrivals of an access slot between
+ * two device steps, with the same libm the reference links.  PRACH_ERR_STREAM: the window is exhausted (the engine retries with a larger one). */
+int prach_noma_activation_stream(const prach_cfg *c, const int32_t *stream, uint64_t *pos, uint64_t avail, int32_t *preamble0, int32_t *sector,
+                                 double *gain, double *lgain) {
+    if (!c || !stream || !pos || !preamble0 || !sector || !gain || !lgain) return PRACH_ERR_ARG;
+    const float pi = 3.14; /* NOMA.c:55 */
+    const float cellRadius = c->cellRadius;
+    uint64_t k = *pos;
+#define DRAW() (k < avail ? (int)stream[k++] : (k++, -1))
+    *preamble0 = DRAW() % c->nPreamble; /* NOMA.c:133 */
+    float angle = (float)DRAW() / (float)(2147483647) * 2 * pi; /* NOMA.c:142 */
+    int sec;
+    if (angle >= 0 && angle < ((1. / 3.) * pi)) sec = 0; /* NOMA.c:146-163 */
+    else if (angle >= ((1. / 3.) * pi) && angle < ((2. / 3.) * pi)) sec = 1;
+    else if (angle >= ((2. / 3.) * pi) && angle < 3.14) sec = 2;
+    else if (angle >= pi && angle < ((4. / 3.) * pi)) sec = 3;
+    else if (angle >= ((4. / 3.) * pi) && angle < ((5. / 3.) * pi)) sec = 4;
+    else sec = 5;
+    *sector = sec;
+    float r;
+    while (1) { /* NOMA.c:167-172 */
+        if (k >= avail) return PRACH_ERR_STREAM;
+        r = cellRadius * sqrt((float)DRAW() / (float)2147483647);
+        if (r > 35.0) break;
+    }
+    float x = r * cos(angle), y = r * sin(angle), pathloss; /* NOMA.c:176-178 */
+    double env = sqrt(x * x + y * y);
+    double ch_g = 0, rayleigh;
+    while (ch_g < 1e-7) { /* NOMA.c:185-189 */
+        if (k >= avail) return PRACH_ERR_STREAM;
+        pathloss = sqrt(1 + pow(env, 2));
+        rayleigh = sqrt(-2 * log((double)DRAW() / (double)2147483647));
+        ch_g = pow(rayleigh / pathloss, 2);
+    }
+#undef DRAW
+    if (k > avail) return PRACH_ERR_STREAM;
+    *gain = ch_g;
+    *lgain = log(ch_g);
+    *pos = k;
     return PRACH_OK;
 }
 

@@ -169,6 +169,10 @@ int prach_noma_activation_table(const prach_cfg *cfg, int32_t *preamble0, int32_
 /* the same for the UEs [lo, hi) only (outputs indexed from lo): ranges are independent, the engine builds them on all host cores */
 int prach_noma_activation_range(const prach_cfg *cfg, int lo, int hi, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
                                 uint32_t *ndraws);
+/* activeUE for ONE UE in the reference's own rand() stream (glibc mode of the NOMA_C variant): draws stream[*pos...] in the reference's
+ * order, *pos advances; PRACH_ERR_STREAM when the window of `avail` values is exhausted */
+int prach_noma_activation_stream(const prach_cfg *cfg, const int32_t *stream, uint64_t *pos, uint64_t avail, int32_t *preamble0, int32_t *sector,
+                                 double *gain, double *lgain);
 size_t prach_format_noma_line(const prach_cfg *, const prach_result *, char *buf, size_t cap); /* NOMA.c:606-632 */
 
 /* Text surfaces, byte-compatible with the reference (latency values excepted) */

@@ -248,3 +248,43 @@ def test_gpu_noma_nonsector_equals_oracle(pkg, ob, engine):
             engine.set("cluster", 0)
     with pytest.raises(pkg.PrachError):  # the flag belongs to NOMA_C
         engine.run_trials([pkg.make_cfg(1000, variant=pkg.VARIANT_BETA_C, flags=pkg.FLAG_NOMA_NONSECTOR)])
+
+
+@pytest.mark.gpu
+def test_gpu_noma_glibc_reproduces_reference_lines(pkg, ob, engine):
+    """BASELINE config 4 against the REFERENCE'S OWN OUTPUT, no oracle in between: NOMA_C in glibc mode (the arrivals of every access slot
+    activated on the host in stream order with the reference's libm, everything else on the device at the reference's stream positions:
+    prach_noma_glibc.hip), the rand() stream chained over the ten-point sweep of a seed like NOMA.c:644-647 — the lines NOMA.c printed
+    (tests/golden/noma_c.json), for seeds 0 and 7, up to nUE = 100 000."""
+    g, seeds = golden_lines()
+    for seed in (0, 7):
+        off = 0
+        for k, n in enumerate(range(10000, 100001, 10000)):
+            cfg = pkg.make_cfg(n, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_GLIBC, seed=seed, stream_offset=off)
+            (res,), _ = engine.run_trials([cfg])
+            assert res.status == 0
+            off += res.draws
+            assert pkg.format_noma_line(cfg, res).decode().strip() == seeds[seed][k], (seed, n)
+
+
+@pytest.mark.gpu
+def test_gpu_noma_glibc_equals_oracle(pkg, ob, engine):
+    """... and against the oracle in glibc mode, every logged field of every UE, on parameter sets the reference binary cannot take
+    (NOMA.c has no command line), including the cell-wide grouping variant and an early-finishing trial."""
+    cases = [(6000, 3, {}, 0), (20000, 1, dict(nGrantUL=5, nPreamble=64, backoff=7), 0), (9000, 4, dict(maxRarWindow=6), 0),
+             (12000, 5, dict(nPreamble=8, nGrantUL=3, accessTime=3, maxMsg2TxCount=2), 0), (64, 6, dict(nGrantUL=30), 0),
+             (15000, 8, {}, 1), (7000, 9, dict(nGrantUL=1, backoff=3, max_steps=3000), 1)]
+    for nUE, seed, kw, nonsector in cases:
+        cfg = pkg.make_cfg(nUE, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_GLIBC, seed=seed, flags=pkg.FLAG_NOMA_NONSECTOR if nonsector else 0, **kw)
+        (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+        okw = dict(kw)
+        if "maxMsg2TxCount" in okw:
+            okw["maxMsg1ReTx"] = okw.pop("maxMsg2TxCount")
+        ocfg = ob.make_noma_cfg(nUE, nonsector=nonsector, **okw)
+        ores, oues = ob.noma_run_trial(ocfg, ob.Rng(ob.RNG_GLIBC, seed))
+        assert (res.status, res.nSuccessUE, res.sumTimer, res.preambleTxCount, res.failCounts, res.activeCheck, res.draws, res.time_exit, res.steps) == \
+               (0, ores.nSuccessUE, ores.delay, ores.nTxP, ores.raFailedUEs, ores.activeCheck, ores.draws, ores.time_exit, ores.steps), (nUE, seed, kw)
+        a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16)
+        b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
+        diff = np.where((a != b).any(axis=1))[0]
+        assert diff.size == 0, (nUE, seed, kw, diff[:5], a[diff[:3]], b[diff[:3]])
