@@ -94,6 +94,10 @@ __device__ __forceinline__ bool lok(long long g, unsigned tag) {
 }
 __device__ __forceinline__ long long lld(const PRACH_G long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lst(PRACH_G long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lstx(const bool same_xcd, PRACH_G long long *p, long long v) { // same XCD: the line may stay in the shared L2
+    if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ long long lwait(const PRACH_G long long *p, unsigned tag, char *smem) {
     long long g = lld(p);
     unsigned spins = 0;
@@ -108,7 +112,7 @@ __device__ __forceinline__ long long lwait(const PRACH_G long long *p, unsigned 
 // per-trial constants of the step loop (wave-uniform)
 struct LK {
     int nUE, nP, aT, maxRar, maxMsg2, variant, b, G;
-    bool withnoma;
+    bool withnoma, sx;
     unsigned seed_lo, seed_hi, rarlim;
     FastMod fmP, fmB, fmA, fm5;
     PRACH_G int *ptc, *ftt, *stt, *fcnt;
@@ -281,7 +285,7 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
                 const int es = b_ev + __popcll(em & lanemask_lt(lane));
                 const int ispre = (evtype == EVL_CALLER) ? (member_pre && oldp == evp) : (evtype == EVL_RESETCAND ? (evp == evq) : 0);
                 const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
-                if (es < CLUSTER_EVW) lst(mbev + es, lmk((unsigned)i, (unsigned)info, tag));
+                if (es < CLUSTER_EVW) lstx(K.sx, mbev + es, lmk((unsigned)i, (unsigned)info, tag));
             }
             if (eclass) {
                 const int cs = b_cd + __popcll(cm & lanemask_lt(lane));
@@ -355,14 +359,20 @@ __device__ __forceinline__ void l_resolve_reset_candidates(char *smem, const int
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots) {
+__global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots, const int xpack, const int ntrials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
+    int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
+    if (xpack) { // blocks bx and bx + 8 land on the same XCD (observed round-robin dispatch): a cluster = blocks of equal bx % 8
+        const int chunk = blockIdx.x / (8 * G), within = blockIdx.x % (8 * G);
+        T = chunk * 8 + (within & 7); b = within >> 3;
+        if (T >= ntrials) return;
+    }
+    const bool sx = xpack >= 2;
     const TrialDev *const PD = params + T;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     LK K;
     K.nUE = PD->nUE; K.nP = PD->nP; K.aT = PD->aT; K.maxRar = PD->maxRarWindow; K.maxMsg2 = PD->maxMsg2; K.variant = PD->variant;
-    K.b = b; K.G = G;
+    K.b = b; K.G = G; K.sx = sx;
     K.withnoma = K.variant == PRACH_VARIANT_WITHNOMA_C;
     K.seed_lo = PD->seed_lo; K.seed_hi = PD->seed_hi;
     K.rarlim = (unsigned)(K.maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         if (tl >= WG_THREADS - 64 && tl - (WG_THREADS - 64) < nP) { // (the last wavefront: the first ones run the leaver filter)
             const int k = tl - (WG_THREADS - 64);
             const int ml = min(LI(lo::PAR + pc + lo::P_MLOC)[k], LI(lo::PAR + pc + lo::P_MLOCS)[k]);
-            lst(mygr + 1 + k, lmk((unsigned)LI(lo::PAR + pc + lo::P_HIST)[k], ml == INT_MAX ? GRL_NONE : (unsigned)ml, tag));
+            lstx(sx, mygr + 1 + k, lmk((unsigned)LI(lo::PAR + pc + lo::P_HIST)[k], ml == INT_MAX ? GRL_NONE : (unsigned)ml, tag));
         }
 
         // early leavers below this workgroup's lowest caller are the only ones a rank can need
@@ -645,7 +655,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 const int2 c = LI2(lo::LCAND)[k];
                 if (c.x < min(mloc[c.y], mlocs[c.y])) {
                     const int es = atomicAdd(&scal[S_NEV], 1);
-                    if (es < CLUSTER_EVW) lst(mbev + es, lmk((unsigned)c.x, (unsigned)(EVL_LEAVER | (c.y << 4)), tag));
+                    if (es < CLUSTER_EVW) lstx(sx, mbev + es, lmk((unsigned)c.x, (unsigned)(EVL_LEAVER | (c.y << 4)), tag));
                 }
             }
             if (tl == 64) { scal[S_NS] = 0; scal[S_NRC] = 0; scal[S_NRJ] = 0; scal[S_QN] = 0; } // (the queue has been consumed)
@@ -656,7 +666,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
         if (tl == 64) {
             const int nevraw = scal[S_NEV];
-            lst(mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
+            lstx(sx, mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
             scal[S_NEV] = 0; scal[S_NCAND] = 0;
         }
         LSTAMP(5); // publish
@@ -987,7 +997,10 @@ hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, in
     const size_t lds = lcluster_kernel_lds_bytes(lslots);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(lcluster_kernel, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, lslots);
+    const char *xe = getenv("PRACH_XPACK");
+    const int xpack = xe ? atoi(xe) : 0;
+    const int grid = xpack ? ((ntrials + 7) / 8) * 8 * G : ntrials * G;
+    hipLaunchKernelGGL(lcluster_kernel, dim3(grid), dim3(WG_THREADS), lds, stream, params, G, lslots, xpack, ntrials);
     return hipGetLastError();
 }
 

@@ -358,6 +358,26 @@ def test_cli_noma_program(pkg, ob, engine, tmp_path):
     assert (tmp_path / "TestResults" / "Sector_3000_Result.txt").read_text() == exp[0] + exp[3]
 
 
+def test_cli_noma_program_reference_stream(pkg, tmp_path):
+    """prach_sim --program noma --rng glibc: NOMA.c's own program, byte for byte — its first two seeds' stdout (ten chained sweep points
+    each, "Done" after every seed) and the appended per-nUE files, against what the compiled reference printed (tests/golden/noma_c.json)."""
+    from conftest import load_golden
+    g = load_golden("noma_c")
+    lines = g["stdout"].split("\n")
+    want, done = [], 0
+    for l in lines:
+        want.append(l)
+        done += l == "Done"
+        if done == 2:
+            break
+    p = subprocess.run([pkg.CLI_PATH, "--program", "noma", "--rng", "glibc", "--times", "2", "--out", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == "\n".join(want) + "\n"
+    first = [l for l in want if l != "Done"]
+    assert (tmp_path / "TestResults" / "Sector_10000_Result.txt").read_text() == first[0] + "\n" + first[10] + "\n"
+
+
 def test_cli_philox_grid_in_one_call(pkg, ob, engine, tmp_path):
     """--rng philox: the --times x sweep grid is one batched call; stdout order and files follow the reference."""
     p = subprocess.run([pkg.CLI_PATH, "--rng", "philox", "--times", "2", "--sweep", "4000:8000:4000", "--out", str(tmp_path), "--logs", "1"],
