@@ -96,7 +96,7 @@ constexpr int CLUSTER_EVW = 512;   // special-event granules per cluster mailbox
 constexpr int CLUSTER_REC_LFAST = 3; // prach_lcluster.hip: the lean LDS-resident kernel (Philox clusters, nPreamble <= 64)
 size_t lcluster_kernel_lds_bytes(int lslots);
 int lcluster_max_preambles();
-hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, hipStream_t stream);
+hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, int xpack, hipStream_t stream);
 int lcluster_kernel_blocks_per_cu(int lslots);
 constexpr int CLUSTER_LQCAP = 4096; // LDS-resident clusters: owned UE slots per workgroup at most (= the event queue)
 constexpr size_t CLUSTER_LDS_LIMIT = 160 * 1024; // LDS per CU (MI355X_MICROARCH.md): one LDS-resident cluster workgroup per CU

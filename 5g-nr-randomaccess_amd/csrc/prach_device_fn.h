@@ -51,6 +51,21 @@ __device__ __forceinline__ unsigned long long lanemask_le(int lane) {
 }
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
+// Wavefront prefix sum / sum on the DPP network: six dependent VALU instructions (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3) instead of six ds_bpermute round trips through the LDS pipeline
+// (__shfl_up/__shfl_down: >= 64 cycles each plus an lgkmcnt wait) — these sit on the subframe's dependent chain.  Every lane of the
+// wavefront must be active (a lane that is not contributes the `old` operand, 0, to its readers).
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_add(const int x) {
+    return x + __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_scan_incl(int x) {
+    x = dpp_add<0x111, 0xf>(x); x = dpp_add<0x112, 0xf>(x); x = dpp_add<0x114, 0xf>(x); x = dpp_add<0x118, 0xf>(x);
+    x = dpp_add<0x142, 0xa>(x); // row_bcast:15, rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x); // row_bcast:31, rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ int wave_sum(const int x) { return __builtin_amdgcn_readlane(wave_scan_incl(x), 63); } // wave-uniform
+
 
 // ---------------------------------------------------------------------------------------------
 // Device memory is addressed in the GLOBAL address space, explicitly.  The per-trial pointers reach a kernel

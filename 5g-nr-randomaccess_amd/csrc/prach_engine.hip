@@ -49,6 +49,8 @@ struct prach_engine {
 #else
     int64_t opt_lds_records = 1;   // 0: clusters keep their UE records in global memory (diagnostic)
 #endif
+    int64_t opt_xcd_pack = 1;      // 1: lean clusters are launched XCD-packed (a cluster per XCD; granules stay in that XCD's L2 once verified)
+    bool pack_off = false;         // (set for the rerun of a packed launch that timed out)
     int64_t opt_two_per_cu = 0;    // 1: the streaming regime on the small LDS layout, two 1024-thread workgroups per CU (measured slower: DESIGN.md section 4)
     int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
     int num_cus = 256;
@@ -367,7 +369,13 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         const int lslots = lds_record_slots(e, cfgs, idx, m, G, maxP);
         const int rec_mode = use_fast_kernel(e, lslots, maxP) ? CLUSTER_REC_LFAST : (lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16));
         e->last.rec_mode = rec_mode;
-        if (rec_mode == CLUSTER_REC_LFAST) HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, e->stream));
+        if (rec_mode == CLUSTER_REC_LFAST) {
+            // XCD-packed launch (prach_lcluster.hip): each cluster on one XCD, eight clusters side by side — when the clusters of the
+            // launch fit the XCDs' CUs that way (one workgroup per CU: the LDS-resident state fills it)
+            const int xpack = e->opt_xcd_pack && !e->pack_off && G > 1 && ((m + 7) / 8) * G <= e->num_cus / 8;
+            e->last.xcd_packed = xpack;
+            HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, xpack, e->stream));
+        }
         else {
             // the streaming layout (two 1024-thread workgroups = two independent trials per CU): one workgroup per trial, Philox, <= 64 preambles
             const int small = rec_mode == CLUSTER_REC_H8 && rng_mode == PRACH_RNG_PHILOX && maxP <= cluster_small_max_preambles() && e->opt_two_per_cu;
@@ -562,15 +570,26 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
                 int rc = run_group(e, cfgs, todo.data(), (int)todo.size(), results, ue_logs, attempt, G, kernel_ms, upload_ms);
                 if (rc != PRACH_OK) return rc;
                 std::vector<int> again;
+                const bool was_packed = e->last.xcd_packed != 0;
+                e->pack_off = false;
                 for (int k : todo) {
                     if (results[k].status == PRACH_ERR_STREAM) again.push_back(k);         // glibc: draw-stream window ran out: larger one
+                    else if (results[k].status == PRACH_ERR_TIMEOUT && was_packed) {       // the packed placement did not hold: plain cluster launch
+                        again.push_back(k);
+                        e->pack_off = true;
+                    }
                     else if (results[k].status == PRACH_ERR_INTERNAL || results[k].status == PRACH_ERR_TIMEOUT) {
                         fallback.push_back(k);
                         nto += results[k].status == PRACH_ERR_TIMEOUT;
                     }
                 }
+                if (e->pack_off) {
+                    std::fprintf(stderr, "[prach] %zu trial(s) of an XCD-packed cluster launch timed out waiting for a peer workgroup: rerun as a plain cluster launch\n", again.size());
+                    e->last.spin_timeouts += (int32_t)again.size();
+                }
                 todo.swap(again);
             }
+            e->pack_off = false;
             idx.swap(fallback);
             if (idx.empty()) continue;
             note_fallback(e, "trial_kernel (one workgroup per trial, no per-subframe capacity)", idx.size(), nto, G);
@@ -637,6 +656,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "host_threads") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_host_threads = value; return PRACH_OK; }
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "xcd_pack") == 0) { e->opt_xcd_pack = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "two_per_cu") == 0) { e->opt_two_per_cu = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }

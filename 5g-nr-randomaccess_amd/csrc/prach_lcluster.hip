@@ -50,7 +50,7 @@ constexpr int EVL_CALLER = 1, EVL_RESETCAND = 2, EVL_RJOIN = 3, EVL_LEAVER = 4; 
 
 // scalars in LDS
 enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_NEV = 8, S_NCAND, S_NSUCCTOT = 11, S_PTC = 13, S_FC, S_SUMT = 16,
-       S_ND = 18, S_NCROSS = 20, S_QN = 22, S_NRQ = 23,
+       S_ND = 18, S_NCROSS = 20, S_QN = 22, S_NRQ = 23, S_SX = 24,
        // what every thread needs behind S3, in ONE 16-byte LDS read: status, gathered events, overflow flag, events beyond round 1
        S_STATUS = 28, S_NTOT = 29, S_OVF = 30, S_NREM = 31 };
 
@@ -94,7 +94,11 @@ __device__ __forceinline__ bool lok(long long g, unsigned tag) {
 }
 __device__ __forceinline__ long long lld(const PRACH_G long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lst(PRACH_G long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void lstx(const bool same_xcd, PRACH_G long long *p, long long v) { // same XCD: the line may stay in the shared L2
+// A cluster whose workgroups have VERIFIED (handshake before the step loop) that they all run on one XCD shares that XCD's L2: its
+// granule stores may then stay in L2 (workgroup-scope store: no write-through to the fabric), where the peers' `sc1` loads — which
+// bypass only the per-CU L1 — find them after an L2 round trip instead of a fabric one (guide: `sc1` stores DROP the line from the
+// XCD's L2, plain / `sc0` stores KEEP it).  Any other placement keeps the write-through stores.
+__device__ __forceinline__ void lstx(const bool same_xcd, PRACH_G long long *p, long long v) {
     if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -362,17 +366,19 @@ __device__ __forceinline__ void l_resolve_reset_candidates(char *smem, const int
 __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots, const int xpack, const int ntrials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
-    if (xpack) { // blocks bx and bx + 8 land on the same XCD (observed round-robin dispatch): a cluster = blocks of equal bx % 8
+    if (xpack) {
+        // XCD-packed launch: blocks bx and bx + 8 are dealt to the same XCD (observed round-robin dispatch, for speed only — the
+        // handshake below checks it), so a cluster is made of the blocks of equal bx % 8 of one chunk of 8 G blocks, and eight
+        // clusters — one per XCD — share a chunk.  Blocks of trials past the last one leave at once.
         const int chunk = blockIdx.x / (8 * G), within = blockIdx.x % (8 * G);
         T = chunk * 8 + (within & 7); b = within >> 3;
         if (T >= ntrials) return;
     }
-    const bool sx = xpack >= 2;
     const TrialDev *const PD = params + T;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     LK K;
     K.nUE = PD->nUE; K.nP = PD->nP; K.aT = PD->aT; K.maxRar = PD->maxRarWindow; K.maxMsg2 = PD->maxMsg2; K.variant = PD->variant;
-    K.b = b; K.G = G; K.sx = sx;
+    K.b = b; K.G = G; K.sx = false;
     K.withnoma = K.variant == PRACH_VARIANT_WITHNOMA_C;
     K.seed_lo = PD->seed_lo; K.seed_hi = PD->seed_hi;
     K.rarlim = (unsigned)(K.maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
@@ -455,9 +461,30 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     if (tid < 64) scal[tid] = 0;
     __syncthreads();
 
+    // ---- same-XCD handshake: every workgroup publishes the id of the XCD it runs on (write-through granule, tag 0xFFFF, in the
+    // header of its parity-1 mailbox — first used by subframe 1, which no workgroup reaches before every peer is past this point,
+    // because subframe 0's exchange needs every peer's subframe-0 granules) and reads all G of them: the cluster keeps its granules
+    // in L2 only if they are all equal.  Every workgroup reads the same G values, so all decide alike.
+    if (xpack && G > 1 && G <= 64) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xfu;
+        PRACH_G long long *const hs = mbox + parstride;
+        if (tid == 0) lst(hs + myoff, lmk(xcc, 0u, 0xFFFFu));
+        if (tid < 64) {
+            bool same = true;
+            if (tid < G) same = ((unsigned)lwait(hs + (unsigned)tid * mbs, 0xFFFFu, smem) & 0xFFFFFu) == xcc;
+            const bool all = __ballot(!same) == 0ull;
+            if (tid == 0) scal[S_SX] = all ? 1 : 0;
+        }
+        __syncthreads();
+        K.sx = scal[S_SX] != 0 && scal[S_STATUS] == PRACH_OK;
+    }
+    const bool sx = K.sx;
+
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
     unsigned long long steps = 0;
-    int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || G > 64 || lgroups > 64 * NW) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || G > 64 || lgroups > 64 * NW || stop >= 0xFFFE) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
     unsigned long long deadmask = 0; // bit m: this wavefront's m-th group (local group w + NW * m) is finished for good
     int t5 = 0, tA = 0, slotA = 0;   // t mod 5, t mod accessTime, t / accessTime: kept incrementally
     // arrival table entry of the NEXT access slot: fetched one slot ahead by a VECTOR load whose result is only made scalar
@@ -524,7 +551,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             if (hm) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&scal[S_QN], __popcll(hm));
-                base = __shfl(base, 0);
+                base = __builtin_amdgcn_readlane(base, 0);
                 if (heavy) queue[base + __popcll(hm & lanemask_lt(lane))] = sl; // (the queue has room for every owned slot)
             }
         }
@@ -578,9 +605,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             }
         }
         if (__any((my_coll | my_txop) != 0)) {
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { my_coll += __shfl_down(my_coll, d); my_txop += __shfl_down(my_txop, d); }
-            if (lane == 0) { if (my_coll) atomicAdd(&scal[S_COLL], my_coll); if (my_txop) atomicAdd(&scal[S_TXOP], my_txop); }
+            const int sc_ = wave_sum(my_coll), st_ = wave_sum(my_txop);
+            if (lane == 0) { if (sc_) atomicAdd(&scal[S_COLL], sc_); if (st_) atomicAdd(&scal[S_TXOP], st_); }
         }
     };
     int pendN = -1, pendFa = 0; // deferred calls of the previous subframe (pendN < 0: none)
@@ -628,11 +654,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 l_step(smem, K, lrec, lnd, ldraw, pc, fb, t, prevAC, mbev, tag, lane, i, sl, v && i < activeCheck, r, ndc, c_succ, c_contf);
             }
             if (__any((c_succ | c_contf) != 0)) {
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+                const int ss_ = wave_sum(c_succ), sf_ = wave_sum(c_contf);
                 if (lane == 0) {
-                    if (c_succ) atomicAdd(&scal[S_NSUCC], c_succ);
-                    if (c_contf) atomicAdd(&scal[S_CONTF], c_contf);
+                    if (ss_) atomicAdd(&scal[S_NSUCC], ss_);
+                    if (sf_) atomicAdd(&scal[S_CONTF], sf_);
                 }
             }
         }
@@ -730,13 +755,11 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     const unsigned w0 = (unsigned)g_ & 0xFFFFFu;
                     nev = (int)(w0 & 0x1FFFu); ovf = (int)((w0 >> 13) & 1u); nsuc = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu);
                 }
-                int x = nev;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (hl >= d) x += y; }
+                const int x = wave_scan_incl(nev); // (the whole wavefront is here: hl = lane)
                 LI(lo::EVOFF)[hl] = x - nev;
-                int rem = max(nev - LEPF, 0); // events beyond the granules fetched in round 1
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) { nsuc += __shfl_down(nsuc, d); ovf |= __shfl_down(ovf, d); rem += __shfl_down(rem, d); }
+                const int rem = wave_sum(max(nev - LEPF, 0)); // events beyond the granules fetched in round 1
+                nsuc = wave_sum(nsuc);
+                ovf = __ballot(ovf != 0) != 0ull;
                 if (hl == 63) { scal[S_NTOT] = x; LI(lo::EVOFF)[64] = x; }
                 if (hl == 0) scal[S_NREM] = rem;
                 if (hl == 0) { scal[S_NSUCCTOT] = nsuc; scal[S_OVF] = ovf; }
@@ -859,9 +882,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             __syncthreads();
             {
                 const int c = bins[tl];
-                int x = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+                const int x = wave_scan_incl(c);
                 if (lane == 63) wtot[w] = x;
                 __syncthreads();
                 int add = 0;
@@ -993,12 +1014,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
 size_t lcluster_kernel_lds_bytes(int lslots) { return (size_t)lo::TAIL + (size_t)lslots * 28; }
 int lcluster_max_preambles() { return NPCL; }
 
-hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, hipStream_t stream) {
+hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, int xpack, hipStream_t stream) {
     const size_t lds = lcluster_kernel_lds_bytes(lslots);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    const char *xe = getenv("PRACH_XPACK");
-    const int xpack = xe ? atoi(xe) : 0;
     const int grid = xpack ? ((ntrials + 7) / 8) * 8 * G : ntrials * G;
     hipLaunchKernelGGL(lcluster_kernel, dim3(grid), dim3(WG_THREADS), lds, stream, params, G, lslots, xpack, ntrials);
     return hipGetLastError();

@@ -114,7 +114,7 @@ typedef struct prach_timing {
     int32_t spin_timeouts;   /* ... of which: peer waits that timed out (PRACH_ERR_TIMEOUT) */
     int32_t rec_mode;        /* last cluster launch: 0 records in global memory (16 B), 1 global 8 + 4 B (one workgroup per trial),
                                 2 resident in LDS for the whole trial (clusters, Philox) */
-    int32_t reserved;
+    int32_t xcd_packed;   /* 1: the last cluster launch was XCD-packed (each cluster on the CUs of one XCD; prach_engine_set "xcd_pack") */
     uint64_t group_visits;   /* cluster_kernel (records in global memory): 64-UE group visits of the pass's phase A, summed over the call */
     uint64_t event_ues;      /* ... and UEs that went through its full event body: the kernel's OWN memory work, for a roofline built
                                 from the bytes it really moves (a visit reads one hot record per lane, an event reads and writes a UE) */
