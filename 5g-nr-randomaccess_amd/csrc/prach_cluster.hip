@@ -910,7 +910,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
     unsigned long long base = 0; // glibc: rand() calls consumed so far (relative to the stream window)
 #ifdef PRACH_STAMPS
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-    unsigned long long fstamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = tprev;
+    unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = tprev;
     unsigned long long statN = 0, maxN = 0, statRC = 0, statNS = 0, maxNS = 0;
 #endif
 
@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
         if (b == 0) {
 #ifdef PRACH_STAMPS
             for (int k = 0; k < 8; k++) o->stamps6[k] = stamps[k];
-            for (int k = 0; k < 16; k++) o->fstamps[k] = fstamps[k];
+            for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];
             o->dbg[0] = statN; o->dbg[1] = maxN; o->dbg[2] = statRC; o->dbg[3] = (statNS << 20) | maxNS;
 #endif
             o->time_exit = time_exit;

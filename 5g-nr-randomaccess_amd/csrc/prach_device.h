@@ -45,7 +45,7 @@ struct DevResult {
     long long sumTimer;
     unsigned long long dbg[4];
     unsigned long long stamps6[8]; // diagnostic build: cycles per phase (pass, publish, barrier, gather, resolve, grants)
-    unsigned long long fstamps[16]; // diagnostic build: finer split (prach_cluster.hip FSTAMP)
+    unsigned long long fstamps[24]; // diagnostic build: finer split (prach_cluster.hip FSTAMP)
     unsigned long long visits, events; // cluster_kernel: 64-UE group visits of the compacted pass's phase A, UEs through its phase B (the
                                        // kernel's OWN memory work: a visit reads one hot record per lane, an event reads and writes a UE)
 };

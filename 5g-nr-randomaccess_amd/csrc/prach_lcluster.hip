@@ -28,10 +28,13 @@ namespace prach {
 namespace {
 
 #ifdef PRACH_STAMPS
+// (accumulated in LDS behind the UE state, not in registers: 24 64-bit accumulators in registers made the diagnostic build spill the
+//  exchange's address registers to scratch and serialise its loads — a profile of the profiler)
 #define LSTAMP(k)                                                                                      \
     do {                                                                                               \
         if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); fstamps[k] += now_ - fprev; fprev = now_; } \
     } while (0)
+static_assert(4 * RCCAP >= 8 * 28, "diagnostic accumulators");
 #else
 #define LSTAMP(k) do { } while (0)
 #endif
@@ -54,6 +57,7 @@ enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_NEV = 8, S_NC
        // what every thread needs behind S3, in ONE 16-byte LDS read: status, gathered events, overflow flag, events beyond round 1
        S_STATUS = 28, S_NTOT = 29, S_OVF = 30, S_NREM = 31 };
 
+constexpr int SCHR = 32; // arrival-table ring (power of two; lives in the upper half of the 64 LDS scalars)
 // ---- LDS layout: byte offsets, all compile-time -------------------------------------------------------------------
 namespace lo {
 constexpr int GEV = 0;                          // int2 [LEV] gathered events
@@ -61,6 +65,7 @@ constexpr int SIDX = GEV + 8 * LEV;             // int [LSC]
 constexpr int RCL = SIDX + 4 * LSC;             // int [RCCAP]
 constexpr int SCAL = RCL + 4 * RCCAP;           // int [64]
 constexpr int EVOFF = SCAL + 4 * 64;            // int [64 + 16]
+constexpr int SCHED = SCAL + 4 * 32;            // int [SCHR] ring over the arrival table (activeCheck of the next SCHR / 2 .. SCHR access slots): the upper half of SCAL
 constexpr int BINS = EVOFF + 4 * 80;            // int [LGB]
 constexpr int WTOT = BINS + 4 * LGB;            // int [NW]
 constexpr int PAR = WTOT + 4 * NW;              // per subframe parity: HIST, MLOC, MLOCS, CANDN, each [NPCL]
@@ -458,7 +463,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             LI(lo::TOTAL + par * lo::RBSZ)[tid] = 0; LI(lo::NLV + par * lo::RBSZ)[tid] = 0; LI(lo::FIE + par * lo::RBSZ)[tid] = 0;
         }
     }
-    if (tid < 64) scal[tid] = 0;
+    if (tid < 32) scal[tid] = 0;
+    if (tid < SCHR) LI(lo::SCHED)[tid] = ((const PRACH_G int *)PD->sched)[min(tid, PD->maxTime / K.aT + 1)];
     __syncthreads();
 
     // ---- same-XCD handshake: every workgroup publishes the id of the XCD it runs on (write-through granule, tag 0xFFFF, in the
@@ -490,10 +496,16 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     // arrival table entry of the NEXT access slot: fetched one slot ahead by a VECTOR load whose result is only made scalar
     // (v_readfirstlane) when the slot begins — a scalar use right behind the load would park the wave for a full L2 round trip
     // on the subframe's critical chain once per access slot
-    int acNextV = sched[0];
+    // — and through an LDS ring over the table (refilled by half every SCHR / 2 slots): a global load here would make the compiler wait
+    // with vmcnt(0), i.e. also for the exchange's granule loads issued just before phase A of the next subframe
+    int *const ring = LI(lo::SCHED);
+    const int nsched = PD->maxTime / aT + 2; // entries of the table (prach_engine.hip)
+    int acNextV = ring[0];
 #ifdef PRACH_STAMPS
-    unsigned long long fstamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
-    unsigned long long dstat[4] = {0, 0, 0, 0}; // thread 0: sum of queue lengths, round-1 bucket / event granules read again, refills
+    unsigned long long *const fstamps = reinterpret_cast<unsigned long long *>(smem + lo::RCL + 4 * (RCCAP - 56)); // [24] + dstat[4]: the reset-candidate list's space (a trial that has such candidates garbles its profile)
+    unsigned long long *const dstat = fstamps + 24; // thread 0: sum of queue lengths, round-1 bucket / event granules read again, refills
+    if (tid < 28) fstamps[tid] = 0;
+    unsigned long long fprev = __builtin_readcyclecounter();
 #define LSTAT(k, v) do { if (threadIdx.x == 0) dstat[k] += (unsigned long long)(v); } while (0)
 #else
 #define LSTAT(k, v) do { } while (0)
@@ -622,7 +634,9 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         const int prevAC = activeCheck;
         if (tA == 0 && activeCheck != nUE) { // Beta.c:121-134: this access slot's arrivals (fetched a slot ago)
             activeCheck = __builtin_amdgcn_readfirstlane(acNextV);
-            acNextV = sched[slotA + 1]; // (the table has maxTime / accessTime + 2 entries)
+            acNextV = ring[(slotA + 1) & (SCHR - 1)];
+            if (slotA > 0 && (slotA & (SCHR / 2 - 1)) == 0 && tid < SCHR / 2) // the half of the ring that has just been used up
+                ring[(slotA + SCHR / 2 + tid) & (SCHR - 1)] = sched[min(slotA + SCHR / 2 + tid, nsched - 1)];
         }
         const int parity = t & 1;
         const unsigned tag = (unsigned)(t + 1);
@@ -708,12 +722,14 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
 #pragma unroll
         for (int u = 0; u < 2; u++)
             if (r2wg[u] >= 0) ev2[u] = lld(mbpar + r2off[u]);
+        LSTAMP(16);
         if (ahead) {
             // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the pass of
             // subframe t left them
             const int acN = (tA + 1 == aT && activeCheck != nUE) ? __builtin_amdgcn_readfirstlane(acNextV) : activeCheck;
             phase_a(true, t + 1, activeCheck, acN, pn);
         }
+        LSTAMP(17);
         { // refill: the next two draws of every UE that drew in this subframe's phase B (off the chain: the exchange is in flight)
             const int nrq = min(scal[S_NRQ], LRQ);
             LSTAT(3, scal[S_NRQ]);
@@ -726,6 +742,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 lnd[sl] = nd | ND_READY;
             }
         }
+        LSTAMP(18);
         if (pendN >= 0) { calls(pendFa, pendN, false); pendN = -1; } // the previous subframe's deferred calls (its event list is intact until S3)
         LSTAMP(6); // phase A ahead
         {
@@ -747,6 +764,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 if (h) atomicAdd(&total[p], (int)h);
                 if (ml != GRL_NONE) atomicMin(&fcallA[p], (int)ml);
             }
+            LSTAMP(19);
             if (hl >= 0) {
                 int nev = 0, nsuc = 0, ovf = 0;
                 if (hl < G) {
@@ -999,7 +1017,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         if (status != PRACH_OK) gmin(&o->status, status);
         if (b == 0) {
 #ifdef PRACH_STAMPS
-            for (int k = 0; k < 16; k++) o->fstamps[k] = fstamps[k];
+            for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];
             for (int k = 0; k < 4; k++) o->dbg[k] = dstat[k];
 #endif
             o->time_exit = time_exit;
