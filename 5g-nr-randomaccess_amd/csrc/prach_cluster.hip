@@ -443,9 +443,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         }
     } else if (MODE == 2) { // the reference's own stream: position = draws before this subframe's UE loop + index-ordered prefix
         if (__any(need > 0)) {
-            int x = need;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            const int x = wave_scan_incl(need);
             const unsigned long long o = stepbase + (unsigned long long)L.gpre[g] + (unsigned long long)(x - need);
             if (need > 0) d1 = P.stream[o];
             if (need > 1) d2 = P.stream[o + 1];
@@ -530,7 +528,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         if (em) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_NEV], __popcll(em));
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readlane(base, 0);
             if (evtype != 0) {
                 const int slot = base + __popcll(em & lanemask_lt(lane));
                 const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
@@ -543,7 +541,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         if (cm) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_NCAND], __popcll(cm));
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readlane(base, 0);
             if (eclass) {
                 const int cs = base + __popcll(cm & lanemask_lt(lane));
                 if (CX::LREC && cs < LCANDCAP) C.lcand[cs] = make_int2(i, oldp);
@@ -601,8 +599,7 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
         ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, g, j, i, j * 64 + lane, i < activeCheck, r, ndc, c_succ, c_contf);
     }
     if (!FINAL) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        c_succ = wave_sum(c_succ); c_contf = wave_sum(c_contf); // (DPP: prach_device_fn.h)
         if (lane == 0) {
             if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
             if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
@@ -704,7 +701,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
             const int n = __popcll(hm);
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_QN], n);
-            base = __shfl(base, 0);
+            base = __builtin_amdgcn_readlane(base, 0);
             if (CX::LREC || base + n <= CX::QCAPX) { // (LDS-resident: the queue holds slots and has room for every owned UE)
                 if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = CX::LREC ? j * 64 + lane : i;
             } else if (SPEC) { // cannot happen: the kernel runs ahead only if every owned UE fits the queue
@@ -742,8 +739,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     if (!hooked) late_hook();
     if (lane == 0 && nvisit) atomicAdd(&L.scal[C_VISITS], nvisit); // (reported, never read by the simulation)
     if (!SPEC && __any((c_succ | c_contf) != 0)) { // (only the in-place overflow path counts here)
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        c_succ = wave_sum(c_succ); c_contf = wave_sum(c_contf); // (DPP: prach_device_fn.h)
         if (lane == 0) {
             if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
             if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
@@ -770,8 +766,7 @@ __device__ __forceinline__ void compact_phase_b(const TrialG &P, const CLds &L, 
         ue_step<MODE>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, stepbase, lane, i >> 6, -1, i, slot, v, r, ndc, c_succ, c_contf);
     }
     if (__any((c_succ | c_contf) != 0)) { // (most wavefronts, most subframes: nothing to add)
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        c_succ = wave_sum(c_succ); c_contf = wave_sum(c_contf); // (DPP: prach_device_fn.h)
         if (lane == 0) {
             if (c_succ) atomicAdd(&L.scal[C_NSUCC], c_succ);
             if (c_contf) atomicAdd(&L.scal[C_CONTF], c_contf);
@@ -1000,9 +995,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
                 int v[4], sum = 0;
 #pragma unroll
                 for (int u_ = 0; u_ < 4; u_++) { const int g = tid * 4 + u_; v[u_] = g < ngroups_t ? L.gsum[g] : 0; sum += v[u_]; }
-                int x = sum;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((tid & 63) >= d) x += y; }
+                const int x = wave_scan_incl(sum);
                 if ((tid & 63) == 63) L.wtot[tid >> 6] = x;
                 __syncthreads();
                 int add = 0;
@@ -1130,12 +1123,10 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
                     const unsigned w0 = (unsigned)g_ & 0xFFFFFu;
                     nev = (int)(w0 & 0x1FFFu); ovf = (int)((w0 >> 13) & 1u); nsuc = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu);
                 }
-                int x = nev;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (l >= d) x += y; }
+                const int x = wave_scan_incl(nev); // (the whole last wavefront is here)
                 L.evoff[l] = x - nev;
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) { nsuc += __shfl_down(nsuc, d); ovf |= __shfl_down(ovf, d); }
+                nsuc = wave_sum(nsuc);
+                ovf = __ballot(ovf != 0) != 0ull;
                 if (l == 63) L.scal[C_NTOT] = x;
                 if (l == 0) { L.scal[C_NSUCCTOT] = nsuc; L.scal[C_OVF] = ovf; }
             }
@@ -1223,8 +1214,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
                 my_coll += 1; my_txop += 1;
             }
         }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { my_coll += __shfl_down(my_coll, d); my_txop += __shfl_down(my_txop, d); }
+        my_coll = wave_sum(my_coll); my_txop = wave_sum(my_txop);
         if ((tid & 63) == 0) { if (my_coll) atomicAdd(&L.scal[C_COLL], my_coll); if (my_txop) atomicAdd(&L.scal[C_TXOP], my_txop); }
         FSTAMP(11); // calls
         __syncthreads(); // S5: calls done; singles listed
@@ -1255,9 +1245,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
             __syncthreads();
             {
                 const int c = L.bins[tid];
-                int x = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if ((tid & 63) >= d) x += y; }
+                const int x = wave_scan_incl(c);
                 if ((tid & 63) == 63) L.wtot[tid >> 6] = x;
                 __syncthreads();
                 int add = 0;

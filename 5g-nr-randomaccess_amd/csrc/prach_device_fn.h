@@ -65,6 +65,14 @@ __device__ __forceinline__ int wave_scan_incl(int x) {
     return x;
 }
 __device__ __forceinline__ int wave_sum(const int x) { return __builtin_amdgcn_readlane(wave_scan_incl(x), 63); } // wave-uniform
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_max(const int x) {
+    return max(x, __builtin_amdgcn_update_dpp(INT_MIN, x, CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_max(int x) { // wave-uniform maximum, same network
+    x = dpp_max<0x111, 0xf>(x); x = dpp_max<0x112, 0xf>(x); x = dpp_max<0x114, 0xf>(x); x = dpp_max<0x118, 0xf>(x);
+    x = dpp_max<0x142, 0xa>(x); x = dpp_max<0x143, 0xc>(x);
+    return __builtin_amdgcn_readlane(x, 63);
+}
 
 
 // ---------------------------------------------------------------------------------------------

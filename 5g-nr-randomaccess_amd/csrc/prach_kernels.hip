@@ -187,16 +187,11 @@ __device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int
         int d1 = 0, d2 = 0;
         if (__any(need > 0)) {
             if (GLIBC) {
-                int x = need;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int y = __shfl_up(x, d);
-                    if (lane >= d) x += y;
-                }
+                const int x = wave_scan_incl(need); // (DPP: prach_device_fn.h)
                 const unsigned long long o = woff + (unsigned long long)(x - need);
                 if (need > 0) d1 = P.stream[o];
                 if (need > 1) d2 = P.stream[o + 1];
-                woff += (unsigned long long)__shfl(x, 63);
+                woff += (unsigned long long)__builtin_amdgcn_readlane(x, 63);
             } else {
                 unsigned k = 0;
                 if (need > 0) k = P.nd[i];
@@ -291,7 +286,7 @@ __device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int
             while (qm) {
                 const int l = __ffsll((long long)qm) - 1;
                 qm &= qm - 1;
-                const int p = __shfl(qp, l);
+                const int p = __builtin_amdgcn_readlane(qp, __builtin_amdgcn_readfirstlane(l));
                 const unsigned long long mm = __ballot(member_pre && oldp == p);
                 if (lane == l) le = L.wavehist[w * nP + p] + __popcll(mm & lanemask_le(lane));
             }
@@ -318,13 +313,11 @@ __device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int
     }
 
     if (MODE == 1) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) wdraw += __shfl_down(wdraw, d);
+        wdraw = (unsigned)wave_sum((int)wdraw);
         if (lane == 0) L.wdraws[w] = wdraw;
     }
     if (MODE == 0 || MODE == 2) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_contf += __shfl_down(c_contf, d); }
+        c_succ = wave_sum(c_succ); c_contf = wave_sum(c_contf);
         if (lane == 0) {
             L.evcnt[w] = evn;
             if (c_succ) { atomicAdd(&L.scal[S_NSUCC], c_succ); atomicAdd(&L.scal[S_FINS], c_succ); }

@@ -208,8 +208,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     ns = (int)((unsigned)g_ & 0xFFFFFu);
                     mt = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu) - 1;
                 }
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) { ns += __shfl_down(ns, d); mt = max(mt, __shfl_down(mt, d)); }
+                ns = wave_sum(ns); mt = wave_max(mt); // (DPP: prach_device_fn.h; the whole wavefront is here)
                 if (l == 0) { L.scal[N_NSUCCTOT] = ns; L.scal[N_MAXTTOT] = mt; }
             }
             __syncthreads();
@@ -388,8 +387,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                 if (has_next) pass_a_lane(i, r, dirty, t0 + aT, activeCheck, acNext);
                 if (dirty) store_rec(&P.rec[i], r);
             }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { c_succ += __shfl_down(c_succ, d); c_maxt = max(c_maxt, __shfl_down(c_maxt, d)); }
+            c_succ = wave_sum(c_succ); c_maxt = wave_max(c_maxt);
             if (lane == 0 && c_succ) { atomicAdd(&L.scal[N_NSUCC], c_succ); atomicMax(&L.scal[N_MAXT], c_maxt); }
         }
         __syncthreads();

@@ -54,9 +54,7 @@ __device__ __forceinline__ int ng_align(int sub, int aT) { // NOMA.c:464-475
 // block-wide exclusive prefix of one int per thread (1024 threads); returns the block total through `tot`
 __device__ __forceinline__ int block_excl_scan(const int v, int *wtot, int &tot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+    const int x = wave_scan_incl(v); // (DPP: prach_device_fn.h)
     __syncthreads(); // (wtot of the previous scan has been read)
     if (lane == 63) wtot[w] = x;
     __syncthreads();
