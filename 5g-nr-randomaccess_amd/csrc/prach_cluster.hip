@@ -120,8 +120,9 @@ __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b
     const int w = j & (NW - 1);
     int m = j / NW;
     if (j >= ngroups) return -1; // (G == 1, b == 0: local group == global group)
-    if ((m >> 5) != dc.widx) { dc.widx = m >> 5; dc.word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]); }
-    unsigned word = dc.word;
+    // (the cached word and its index are wave-uniform and read back as such: kept in scalar registers, compared with s_cmp)
+    if ((m >> 5) != __builtin_amdgcn_readfirstlane(dc.widx)) { dc.widx = m >> 5; dc.word = __builtin_amdgcn_readfirstlane(L.dead[w * DEADWW + (m >> 5)]); }
+    unsigned word = __builtin_amdgcn_readfirstlane(dc.word);
     if (!((word >> (m & 31)) & 1u)) return j; // the common case while a trial is busy: the very next group is live
     for (;;) { // skip finished groups a word at a time
         const unsigned live = ~word >> (m & 31); // bit k: group m + k is live (zeros shifted in from the top = "not in this word")
@@ -569,7 +570,9 @@ __device__ __forceinline__ void cluster_pass(const TrialG &P, const CLds &L, con
     // software pipeline: the next live groups' records (and Philox draw indices) are in flight while the
     // current group is processed
     DeadCache dc{-1, 0u};
-    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups, dc); }; // wave-uniform
+    // (wave-uniform, and SAID so: without the readfirstlane the loop-carried group index is treated as divergent and the whole
+    //  loop control — bitmap walk, range checks, exits — is emitted as vector compares and exec-mask branches)
+    auto next_live = [&](const int jj) -> int { return __builtin_amdgcn_readfirstlane(dead_skip(L, jj, C.b, C.G, ngroups, dc)); };
     // two groups ahead (slots A, B; three ahead measured slower).  The load itself is unconditional (record 0 is always
     // mapped) and the "nothing there" case is applied where the record is consumed: a conditional load would have to be
     // waited for on the spot to merge it with the default value, which serialises the prefetches.
@@ -639,7 +642,9 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     const int nUE = P.nUE, maxRar = P.maxRarWindow;
     int c_succ = 0, c_contf = 0;
     DeadCache dc{-1, 0u};
-    auto next_live = [&](const int jj) -> int { return dead_skip(L, jj, C.b, C.G, ngroups, dc); }; // wave-uniform
+    // (wave-uniform, and SAID so: without the readfirstlane the loop-carried group index is treated as divergent and the whole
+    //  loop control — bitmap walk, range checks, exits — is emitted as vector compares and exec-mask branches)
+    auto next_live = [&](const int jj) -> int { return __builtin_amdgcn_readfirstlane(dead_skip(L, jj, C.b, C.G, ngroups, dc)); };
     // The prefetch is an unconditional load of an in-range record (lanes past the arrived UEs re-read the last one and
     // ignore it): nothing has to be merged with a default value, so nothing is waited for before the record is used.
     const unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
@@ -676,7 +681,7 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
             // nothing happens in this group; retire it for good once every UE in it has finished
             if (__all(done)) {
                 if (lane == 0) dead_mark(L, j, C.G);
-                if (C.G == 1 && ((j / NW) >> 5) == dc.widx) dc.word |= 1u << ((j / NW) & 31); // (the register copy of this wavefront's word)
+                if (C.G == 1 && ((j / NW) >> 5) == __builtin_amdgcn_readfirstlane(dc.widx)) dc.word = __builtin_amdgcn_readfirstlane(dc.word | (1u << ((j / NW) & 31))); // (the register copy of this wavefront's word)
             }
             return;
         }
