@@ -658,33 +658,20 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         const int i = g * 64 + lane;
         const unsigned pk = (unsigned)r.w;
         const unsigned pg = pk >> PK_PEND_SHIFT; // deferred outcome | grant bit << 3
-        const bool act2 = (pk & 2u) != 0u;        // ACT_M1 or ACT_M3
-        const bool isM1 = (pk & 3u) == (unsigned)ACT_M1;
-        const bool haspre = (pk & (0xffu << PK_PRE_SHIFT)) != 0u;
-        const bool contend = isM1 && haspre && r.z <= t; // nowBackoff <= 0: stored as expiry subframe when positive
-        const bool trig = r.x == t;
-        // light: PEND_NONE / PEND_STAY / PEND_CALLER without a grant (pg 0..2), contending, RAR window stays open
-        bool lightc = light_case(pk, r.x, r.z, t, rarlim);
-        // ahead of the resolver of the previous subframe its grants are not known: a new caller (PEND_CALLER) may get one and
-        // waits for phase B; a matched UE (PEND_STAY) that gets one is taken out again by the granting thread (grant_fixup)
-        if (SPEC && pg == (unsigned)PEND_CALLER) lightc = false;
-        bool quiet = pg == 0u && (!act2 || (!contend && !trig && !(isM1 && !haspre)));
-        bool done = (pk & 3u) == (unsigned)ACT_DONE;
-        if (g * 64 + 64 > prevAC) { // the (at most two) groups the arrival front is in: per-lane range checks
-            const bool valid = i < activeCheck, old = i < prevAC;
-            lightc = lightc && old;
-            quiet = !valid || (old && quiet);
-            done = (valid && done) || i >= nUE;
-        }
-        const bool heavy = !lightc && !quiet;
-        if (!__any(lightc || heavy)) {
+        // (ahead of the resolver of the previous subframe — SPEC — its grants are not known: a new caller (PEND_CALLER) may get one and
+        //  waits for phase B; a matched UE (PEND_STAY) that gets one is taken out again by the granting thread: grant_fixup)
+        const PassMasks M = pass_masks<SPEC>(pk, r.x, r.z, t, rarlim, g * 64 + 64 > prevAC, i, activeCheck, prevAC, nUE);
+        const unsigned long long mHeavy = ~(M.light | M.quiet);
+        if ((M.light | mHeavy) == 0ull) {
             // nothing happens in this group; retire it for good once every UE in it has finished
-            if (__all(done)) {
+            if (M.done == ~0ull) {
                 if (lane == 0) dead_mark(L, j, C.G);
                 if (C.G == 1 && ((j / NW) >> 5) == __builtin_amdgcn_readfirstlane(dc.widx)) dc.word = __builtin_amdgcn_readfirstlane(dc.word | (1u << ((j / NW) & 31))); // (the register copy of this wavefront's word)
             }
             return;
         }
+        const bool lightc = __builtin_amdgcn_inverse_ballot_w64(M.light), heavy = __builtin_amdgcn_inverse_ballot_w64(mHeavy);
+        const bool trig = __builtin_amdgcn_inverse_ballot_w64(M.trig);
         if (lightc) { // Beta.c:245 + the txTime++ of Beta.c:346,358
             const bool bump = pg != 0u;
             const bool member = bump || trig; // matched by a preambleCollision scan in this subframe
@@ -701,9 +688,9 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
                 atomicMin(&ml[p1], i); // (fire and forget: a load-compare in front of it is a dependent LDS round trip per group; config 3 +1.5 %)
             }
         }
-        const unsigned long long hm = __ballot(heavy);
+        const unsigned long long hm = mHeavy;
         if (hm) {
-            const int n = __popcll(hm);
+            const int n = __builtin_amdgcn_readfirstlane(__popcll(hm)); // (said to be uniform: the atomic below then needs no per-lane scan)
             int base = 0;
             if (lane == 0) base = atomicAdd(&L.scal[C_QN], n);
             base = __builtin_amdgcn_readlane(base, 0);

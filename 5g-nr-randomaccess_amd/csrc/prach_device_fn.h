@@ -157,6 +157,40 @@ __device__ __forceinline__ void store_log(PRACH_G v4i_t *logs, const int i, cons
     }
 }
 // agent-scope relaxed read-modify-writes on global memory (results of a trial)
+// ---- phase A's classification of one 64-UE group, as lane masks ----------------------------------------------------------
+// Every predicate is ONE vector compare that writes a 64-bit lane mask; the boolean algebra on them runs on the scalar unit
+// (written as `bool`s the compiler kept turning masks into 0/1 vector values and back across the merges: ~10 of the ~30 vector
+// instructions of a group visit, in a pass that is bound by vector issue).  All 64 lanes must be active.
+//   light: PEND_NONE / PEND_STAY / PEND_CALLER without a grant (pg 0..2), contending, RAR window stays open after this subframe
+//          (a PEND_STAY record may be `age` subframes old — written at subframe rx, not touched since: rarWindow has grown by age);
+//          SPEC (ahead of the previous subframe's resolver): a new caller may still get a grant and waits for phase B
+//   quiet: nothing to do;  done: finished for good;  trig: txTime == t
+struct PassMasks { unsigned long long light, quiet, done, trig; };
+template <bool SPEC>
+__device__ __forceinline__ PassMasks pass_masks(const unsigned pk, const int rx, const int rz, const int t, const unsigned rarlim, const bool front,
+                                                const int i, const int acNow, const int acPrev, const int nUE) {
+    typedef unsigned long long u64;
+    const unsigned top = pk & 0xF0000000u; // deferred outcome | grant bit
+    const u64 mM1 = __ballot((pk & 3u) == (unsigned)ACT_M1), mPre = __ballot((pk & (0xffu << PK_PRE_SHIFT)) != 0u);
+    const u64 mBo = __ballot(rz <= t); // nowBackoff <= 0: stored as expiry subframe when positive
+    const u64 mTrig = __ballot(rx == t);
+    const u64 mPg0 = __ballot(pk < (1u << PK_PEND_SHIFT)), mAct2 = __ballot((pk & 2u) != 0u); // ACT_M1 or ACT_M3
+    u64 mDone = __ballot((pk & 3u) == (unsigned)ACT_DONE);
+    const u64 mCont = mM1 & mPre & mBo;
+    const unsigned age = top == ((unsigned)PEND_STAY << PK_PEND_SHIFT) ? (unsigned)(t - 1 - rx) : 0u;
+    const unsigned rarnow = (pk & (0xffu << PK_RAR_SHIFT)) + (age << PK_RAR_SHIFT);
+    u64 mLight = __ballot(pk < (3u << PK_PEND_SHIFT)) & mCont & __ballot(rarnow < rarlim);
+    if (SPEC) mLight &= ~__ballot(top == ((unsigned)PEND_CALLER << PK_PEND_SHIFT));
+    u64 mQuiet = mPg0 & (~mAct2 | (~mCont & ~mTrig & ~(mM1 & ~mPre)));
+    if (front) { // the (at most two) groups the arrival front is in: per-lane range checks
+        const u64 mValid = __ballot(i < acNow), mOld = __ballot(i < acPrev);
+        mLight &= mOld;
+        mQuiet = ~mValid | (mOld & mQuiet);
+        mDone = (mValid & mDone) | __ballot(i >= nUE);
+    }
+    return PassMasks{mLight, mQuiet, mDone, mTrig};
+}
+
 template <class T> __device__ __forceinline__ void gadd(PRACH_G T *p, const T v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void gmin(PRACH_G T *p, const T v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <class T> __device__ __forceinline__ void gmax(PRACH_G T *p, const T v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -525,26 +525,15 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             const int4 r = lrec[sl];
             const unsigned pk = (unsigned)r.w;
             const unsigned pg = pk >> PK_PEND_SHIFT; // deferred outcome | grant bit << 3
-            const bool act2 = (pk & 2u) != 0u;        // ACT_M1 or ACT_M3
-            const bool isM1 = (pk & 3u) == (unsigned)ACT_M1;
-            const bool haspre = (pk & (0xffu << PK_PRE_SHIFT)) != 0u;
-            const bool contend = isM1 && haspre && r.z <= ta; // nowBackoff <= 0: stored as expiry subframe when positive
-            const bool trig = r.x == ta;
-            bool lightc = l_light(pk, r.x, r.z, ta, K.rarlim);
-            if (SPEC && pg == (unsigned)PEND_CALLER) lightc = false;
-            bool quiet = pg == 0u && (!act2 || (!contend && !trig && !(isM1 && !haspre)));
-            bool done = (pk & 3u) == (unsigned)ACT_DONE;
-            if (g * 64 + 64 > prevA) { // the (at most two) groups the arrival front is in: per-lane range checks
-                const bool valid = i < acA, old = i < prevA;
-                lightc = lightc && old;
-                quiet = !valid || (old && quiet);
-                done = (valid && done) || i >= nUE;
-            }
-            const bool heavy = !lightc && !quiet;
-            if (!__any(lightc || heavy)) {
-                if (__all(done)) deadmask |= 1ull << m; // nothing will ever happen in this group again
+            const PassMasks M = SPEC ? pass_masks<true>(pk, r.x, r.z, ta, K.rarlim, g * 64 + 64 > prevA, i, acA, prevA, nUE)
+                                     : pass_masks<false>(pk, r.x, r.z, ta, K.rarlim, g * 64 + 64 > prevA, i, acA, prevA, nUE);
+            const unsigned long long mHeavy = ~(M.light | M.quiet);
+            if ((M.light | mHeavy) == 0ull) {
+                if (M.done == ~0ull) deadmask |= 1ull << m; // nothing will ever happen in this group again
                 continue;
             }
+            const bool lightc = __builtin_amdgcn_inverse_ballot_w64(M.light), heavy = __builtin_amdgcn_inverse_ballot_w64(mHeavy);
+            const bool trig = __builtin_amdgcn_inverse_ballot_w64(M.trig);
             if (lightc) { // Beta.c:245 + the txTime++ of Beta.c:346,358
                 const bool bump = pg != 0u;
                 const bool member = bump || trig; // matched by a preambleCollision scan in this subframe
@@ -559,10 +548,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     if (__atomic_load_n(&ml[p1], __ATOMIC_RELAXED) > i) atomicMin(&ml[p1], i);
                 }
             }
-            const unsigned long long hm = __ballot(heavy);
+            const unsigned long long hm = mHeavy;
             if (hm) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&scal[S_QN], __popcll(hm));
+                if (lane == 0) base = atomicAdd(&scal[S_QN], __builtin_amdgcn_readfirstlane(__popcll(hm)));
                 base = __builtin_amdgcn_readlane(base, 0);
                 if (heavy) queue[base + __popcll(hm & lanemask_lt(lane))] = sl; // (the queue has room for every owned slot)
             }
