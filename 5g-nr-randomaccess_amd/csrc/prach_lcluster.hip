@@ -28,11 +28,14 @@ namespace prach {
 namespace {
 
 #ifdef PRACH_STAMPS
+#ifndef PRACH_STAMP_TID
+#define PRACH_STAMP_TID 0 // the thread whose clock is read (-DPRACH_STAMP_TID=960: the wavefront that reads the headers)
+#endif
 // (accumulated in LDS behind the UE state, not in registers: 24 64-bit accumulators in registers made the diagnostic build spill the
 //  exchange's address registers to scratch and serialise its loads — a profile of the profiler)
 #define LSTAMP(k)                                                                                      \
     do {                                                                                               \
-        if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); fstamps[k] += now_ - fprev; fprev = now_; } \
+        if (threadIdx.x == PRACH_STAMP_TID) { const unsigned long long now_ = __builtin_readcyclecounter(); fstamps[k] += now_ - fprev; fprev = now_; } \
     } while (0)
 static_assert(4 * RCCAP >= 8 * 28, "diagnostic accumulators");
 #else
@@ -40,6 +43,10 @@ static_assert(4 * RCCAP >= 8 * 28, "diagnostic accumulators");
 #endif
 
 constexpr int NPCL = 64;     // stride of the per-bucket tables (nPreamble <= 64)
+// Wavefronts that walk the UE groups in phase A.  The last one does not: it publishes the bucket granules, reads the headers and builds
+// the event offsets — the chain every other wavefront waits for at S3 (measured: with three group visits of its own in the exchange
+// window it reached S3 ~1 000 cycles after everybody else).
+constexpr int NWA = NW - 1;
 constexpr int LEV = 4096;    // gathered events per subframe
 constexpr int LSC = 2048;    // singleton callers per subframe
 constexpr int LCC = 1024;    // early-leaver candidates per workgroup and subframe
@@ -490,8 +497,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
     unsigned long long steps = 0;
-    int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || G > 64 || lgroups > 64 * NW || stop >= 0xFFFE) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
-    unsigned long long deadmask = 0; // bit m: this wavefront's m-th group (local group w + NW * m) is finished for good
+    int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || G > 64 || lgroups > 64 * NWA || stop >= 0xFFFE) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    unsigned long long deadmask = 0; // bit m: this wavefront's m-th group (local group w + NWA * m) is finished for good
     int t5 = 0, tA = 0, slotA = 0;   // t mod 5, t mod accessTime, t / accessTime: kept incrementally
     // arrival table entry of the NEXT access slot: fetched one slot ahead by a VECTOR load whose result is only made scalar
     // (v_readfirstlane) when the slot begins — a scalar use right behind the load would park the wave for a full L2 round trip
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     unsigned long long *const dstat = fstamps + 24; // thread 0: sum of queue lengths, round-1 bucket / event granules read again, refills
     if (tid < 28) fstamps[tid] = 0;
     unsigned long long fprev = __builtin_readcyclecounter();
-#define LSTAT(k, v) do { if (threadIdx.x == 0) dstat[k] += (unsigned long long)(v); } while (0)
+#define LSTAT(k, v) do { if (threadIdx.x == PRACH_STAMP_TID) dstat[k] += (unsigned long long)(v); } while (0)
 #else
 #define LSTAT(k, v) do { } while (0)
 #endif
@@ -517,8 +524,9 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     auto phase_a = [&](const bool SPEC, const int ta, const int prevA, const int acA, const int pcA) __attribute__((always_inline)) {
         int *const hist = LI(lo::PAR + pcA + lo::P_HIST), *const mloc = LI(lo::PAR + pcA + lo::P_MLOC), *const mlocs = LI(lo::PAR + pcA + lo::P_MLOCS);
         const int ngroups = (acA + 63) >> 6;
+        if (w >= NWA) return; // (the last wavefront is the exchange's: bucket publish, headers, event offsets — see NWA)
         for (int m = 0;; m++) {
-            const int j = w + NW * m, g = b + G * j;
+            const int j = w + NWA * m, g = b + G * j;
             if (g >= ngroups) break;
             if ((deadmask >> m) & 1ull) continue;
             const int sl = j * 64 + lane, i = g * 64 + lane;
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         { // refill: the next two draws of every UE that drew in this subframe's phase B (off the chain: the exchange is in flight)
             const int nrq = min(scal[S_NRQ], LRQ);
             LSTAT(3, scal[S_NRQ]);
-            for (int k = tl; k < nrq; k += WG_THREADS) {
+            for (int k = (tl + WG_THREADS / 2) & (WG_THREADS - 1); k < nrq; k += WG_THREADS) { // (from wavefront 8 on: wavefront 0 has the deferred calls)
                 const int sl = LI(lo::RQ)[k];
                 const int i = l_idx_of(K, sl);
                 const unsigned nd = lnd[sl] & ~ND_READY;
@@ -758,6 +766,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 int nev = 0, nsuc = 0, ovf = 0;
                 if (hl < G) {
                     long long g_ = hv;
+                    LSTAT(2, __popcll(__ballot(!lok(g_, tag))) ? 1 : 0); // (subframes in which a header was late)
                     if (!lok(g_, tag)) g_ = lwait(mbpar + hoff, tag, smem);
                     const unsigned w0 = (unsigned)g_ & 0xFFFFFu;
                     nev = (int)(w0 & 0x1FFFu); ovf = (int)((w0 >> 13) & 1u); nsuc = (int)((unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu);
@@ -796,7 +805,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     const int o0 = evoff[r2wg[u]], nev = evoff[r2wg[u] + 1] - o0;
                     if (r2es[u] < nev) {
                         long long e = ev2[u];
-                        if (!lok(e, tag)) { LSTAT(2, 1); e = lwait(mbpar + r2off[u], tag, smem); }
+                        if (!lok(e, tag)) { e = lwait(mbpar + r2off[u], tag, smem); }
                         const int2 ev = make_int2((int)((unsigned)e & 0xFFFFFu), (int)((unsigned)((unsigned long long)e >> 32) & 0xFFFFFu));
                         gev[o0 + r2es[u]] = ev;
                         l_classify(smem, fa, o0 + r2es[u], ev);
