@@ -59,10 +59,12 @@ constexpr unsigned LSPIN = 1u << 22;
 constexpr int EVL_CALLER = 1, EVL_RESETCAND = 2, EVL_RJOIN = 3, EVL_LEAVER = 4; // (= prach_cluster.hip's EVC_*)
 
 // scalars in LDS
-enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_NEV = 8, S_NCAND, S_NSUCCTOT = 11, S_PTC = 13, S_FC, S_SUMT = 16,
-       S_ND = 18, S_NCROSS = 20, S_QN = 22, S_NRQ = 23, S_SX = 24,
-       // what every thread needs behind S3, in ONE 16-byte LDS read: status, gathered events, overflow flag, events beyond round 1
-       S_STATUS = 28, S_NTOT = 29, S_OVF = 30, S_NREM = 31 };
+enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_NEV = 8, S_NCAND /* = S_NEV + 1: read as a pair; both [2] by subframe parity (+ 2): slots 8..11 */, S_PTC = 13, S_FC, S_SUMT = 16,
+       S_ND = 18, S_NCROSS = 20, S_NRQ = 23, S_SX = 24,
+       S_QN = 26, // [2] event queue length, by subframe parity: phase A of subframe t+1 fills one while phase B of subframe t has just read the other
+       // what every thread needs behind S3, in ONE 16-byte LDS read: status, gathered events | overflow flag << 30, events beyond round 1,
+       // successes of the whole cluster
+       S_STATUS = 28, S_NTOT = 29, S_NREM = 30, S_NSUCCTOT = 31 };
 
 constexpr int SCHR = 32; // arrival-table ring (power of two; lives in the upper half of the 64 LDS scalars)
 // ---- LDS layout: byte offsets, all compile-time -------------------------------------------------------------------
@@ -292,8 +294,8 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
         if (em | cm | rm) {
             int b_ev = 0, b_cd = 0, b_rq = 0;
             if (lane == 0) {
-                if (em) b_ev = atomicAdd(&LI(lo::SCAL)[S_NEV], __popcll(em));
-                if (cm) b_cd = atomicAdd(&LI(lo::SCAL)[S_NCAND], __popcll(cm));
+                if (em) b_ev = atomicAdd(&LI(lo::SCAL)[S_NEV + (pc ? 2 : 0)], __popcll(em));
+                if (cm) b_cd = atomicAdd(&LI(lo::SCAL)[S_NCAND + (pc ? 2 : 0)], __popcll(cm));
                 if (rm) b_rq = atomicAdd(&LI(lo::SCAL)[S_NRQ], __popcll(rm));
             }
             b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd); b_rq = __builtin_amdgcn_readfirstlane(b_rq);
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             const unsigned long long hm = mHeavy;
             if (hm) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&scal[S_QN], __builtin_amdgcn_readfirstlane(__popcll(hm)));
+                if (lane == 0) base = atomicAdd(&scal[S_QN + (ta & 1)], __builtin_amdgcn_readfirstlane(__popcll(hm)));
                 base = __builtin_amdgcn_readlane(base, 0);
                 if (heavy) queue[base + __popcll(hm & lanemask_lt(lane))] = sl; // (the queue has room for every owned slot)
             }
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         { // ---- phase B: the queued UEs through the full body, 64 at a time ----
             int c_succ = 0, c_contf = 0;
             const int sl_first = queue[w * 64 + lane]; // (read together with the queue length: one LDS round trip, not two)
-            const int qn = scal[S_QN];
+            const int qn = scal[S_QN + parity];
             LSTAT(0, qn);
             for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
                 const bool v = q0 + lane < qn;
@@ -683,33 +685,43 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             lstx(sx, mygr + 1 + k, lmk((unsigned)LI(lo::PAR + pc + lo::P_HIST)[k], ml == INT_MAX ? GRL_NONE : (unsigned)ml, tag));
         }
 
-        // early leavers below this workgroup's lowest caller are the only ones a rank can need
+        // early leavers below this workgroup's lowest caller are the only ones a rank can need.  No candidate (the usual case outside
+        // the overloaded part of a trial): the event count is final since S1 and the header leaves at once, without the barrier S2.
         {
-            const int ncand = scal[S_NCAND];
-            const int *const mloc = LI(lo::PAR + pc + lo::P_MLOC), *const mlocs = LI(lo::PAR + pc + lo::P_MLOCS);
-            for (int k = tl; k < ncand; k += WG_THREADS) {
-                const int2 c = LI2(lo::LCAND)[k];
-                if (c.x < min(mloc[c.y], mlocs[c.y])) {
-                    const int es = atomicAdd(&scal[S_NEV], 1);
-                    if (es < CLUSTER_EVW) lstx(sx, mbev + es, lmk((unsigned)c.x, (unsigned)(EVL_LEAVER | (c.y << 4)), tag));
+            int *const nevp = &scal[S_NEV + 2 * parity]; // (this subframe's pair of counters)
+            const int2 nc = *reinterpret_cast<const int2 *>(nevp); // {events so far, early-leaver candidates}
+            int nevraw = nc.x;
+            if (tl == 64) { scal[S_NS] = 0; scal[S_NRC] = 0; scal[S_NRJ] = 0; scal[S_QN + parity] = 0; } // (this subframe's queue has been consumed)
+            if (nc.y > 0) {
+                const int *const mloc = LI(lo::PAR + pc + lo::P_MLOC), *const mlocs = LI(lo::PAR + pc + lo::P_MLOCS);
+                for (int k = tl; k < nc.y; k += WG_THREADS) {
+                    const int2 c = LI2(lo::LCAND)[k];
+                    if (c.x < min(mloc[c.y], mlocs[c.y])) {
+                        const int es = atomicAdd(nevp, 1);
+                        if (es < CLUSTER_EVW) lstx(sx, mbev + es, lmk((unsigned)c.x, (unsigned)(EVL_LEAVER | (c.y << 4)), tag));
+                    }
                 }
+                LSTAMP(3); // leaver filter
+                __syncthreads(); // S2
+                LSTAMP(4);
+                if (tl == 64) nevraw = *nevp;
             }
-            if (tl == 64) { scal[S_NS] = 0; scal[S_NRC] = 0; scal[S_NRJ] = 0; scal[S_QN] = 0; } // (the queue has been consumed)
-        }
-        LSTAMP(3); // leaver filter
-        __syncthreads(); // S2
-        LSTAMP(4);
-        // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
-        if (tl == 64) {
-            const int nevraw = scal[S_NEV];
-            lstx(sx, mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
-            scal[S_NEV] = 0; scal[S_NCAND] = 0;
+            // publish: header {#events, overflow, #successes} (the pair of counters is reset behind S3 — every thread has read it by
+            // then — and used again by the pass of subframe t + 2, two unconditional barriers later)
+            if (tl == 64) lstx(sx, mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
         }
         LSTAMP(5); // publish
         // round 1: the bucket granules of every workgroup and, on the last wavefront, the headers.  The loads are issued, phase A of
         // the NEXT subframe runs while they (and the other workgroups' stores) are in flight, then every granule is checked and, if
         // its tag is still the old one, re-read until it arrives.
         const bool ahead = t + 1 < stop;
+        if (ahead) {
+            // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the pass of
+            // subframe t left them
+            const int acN = (tA + 1 == aT && activeCheck != nUE) ? __builtin_amdgcn_readfirstlane(acNextV) : activeCheck;
+            phase_a(true, t + 1, activeCheck, acN, pn);
+        }
+        LSTAMP(16);
         long long gv[3] = {0, 0, 0}, hv = 0;
 #pragma unroll
         for (int u = 0; u < 3; u++)
@@ -719,13 +731,6 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
 #pragma unroll
         for (int u = 0; u < 2; u++)
             if (r2wg[u] >= 0) ev2[u] = lld(mbpar + r2off[u]);
-        LSTAMP(16);
-        if (ahead) {
-            // subframe t+1: arrivals of its access slot (Beta.c:121-134), then phase A on this workgroup's records as the pass of
-            // subframe t left them
-            const int acN = (tA + 1 == aT && activeCheck != nUE) ? __builtin_amdgcn_readfirstlane(acNextV) : activeCheck;
-            phase_a(true, t + 1, activeCheck, acN, pn);
-        }
         LSTAMP(17);
         { // refill: the next two draws of every UE that drew in this subframe's phase B (off the chain: the exchange is in flight)
             const int nrq = min(scal[S_NRQ], LRQ);
@@ -776,9 +781,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 const int rem = wave_sum(max(nev - LEPF, 0)); // events beyond the granules fetched in round 1
                 nsuc = wave_sum(nsuc);
                 ovf = __ballot(ovf != 0) != 0ull;
-                if (hl == 63) { scal[S_NTOT] = x; LI(lo::EVOFF)[64] = x; }
-                if (hl == 0) scal[S_NREM] = rem;
-                if (hl == 0) { scal[S_NSUCCTOT] = nsuc; scal[S_OVF] = ovf; }
+                if (hl == 63) { scal[S_NTOT] = x | (ovf ? 1 << 30 : 0); LI(lo::EVOFF)[64] = x; }
+                if (hl == 0) { scal[S_NREM] = rem; scal[S_NSUCCTOT] = nsuc; }
             }
         }
         LSTAMP(7); // round-1 granules taken
@@ -790,11 +794,13 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             // the resolver tables of the subframe before (read by this subframe's pass and by its deferred calls, both done): next subframe's [A]
             LI(lo::FCALL + fb)[tl] = INT_MAX; LI(lo::LCALL + fb)[tl] = -1; LI(lo::TOTAL + fb)[tl] = 0; LI(lo::NLV + fb)[tl] = 0; LI(lo::FIE + fb)[tl] = 0;
         }
-        if (tl == 64) scal[S_NRQ] = 0; // (the refill list has been consumed)
-        const int4 ctl = *reinterpret_cast<const int4 *>(&scal[S_STATUS]); // {status, gathered events, overflow, events beyond round 1}
+        if (tl == 64) { scal[S_NRQ] = 0; scal[S_NEV + 2 * parity] = 0; scal[S_NCAND + 2 * parity] = 0; } // (the refill list and this subframe's event / candidate counts have been consumed)
+        // {status, gathered events | overflow << 30, events beyond round 1, successes}.  The status word is looked at HERE only: an error
+        // raised behind S3 (a capacity of the resolver, a time-out of round 2) ends the trial one subframe later — the engine reruns it anyway
+        const int4 ctl = *reinterpret_cast<const int4 *>(&scal[S_STATUS]);
         if (ctl.x != PRACH_OK) { status = ctl.x; time_exit = t; break; }
-        const int N = ctl.y;
-        if (ctl.z || N > LEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on the general kernels
+        const int N = ctl.y & 0x3FFFFFFF;
+        if ((ctl.y >> 30) || N > LEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on the general kernels
         // the event granules: the first LEPF of every mailbox came with round 1 (each by the thread that fetched it), classified
         // against the lowest definite callers; a mailbox with more has the rest read now (a second round trip, rare)
         {
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     }
                 }
             }
-            if (ctl.w > 0) {
+            if (ctl.z > 0) {
                 for (int k = tl; k < N; k += WG_THREADS) {
                     int lo_ = 0, hi_ = G; // workgroup whose segment holds event k
                     while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (evoff[mid] <= k) lo_ = mid; else hi_ = mid; }
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     const int p1 = (int)((pk >> PK_PRE_SHIFT) & 0xffu) - 1;
                     atomicSub(&LI(lo::PAR + pn + lo::P_HIST)[p1], 1);
                     LI(lo::PAR + pn + lo::P_MLOCS)[p1] = INT_MAX;
-                    queue[atomicAdd(&scal[S_QN], 1)] = sl; // ... and its grant is applied by phase B of subframe t+1
+                    queue[atomicAdd(&scal[S_QN + (parity ^ 1)], 1)] = sl; // ... and its grant is applied by phase B of subframe t+1
                 }
             }
         };
@@ -926,16 +932,16 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             }
         }
         grantCheck += ns;
-        const int nsucc_tot = scal[S_NSUCCTOT];
+        const int nsucc_tot = ctl.w;
         LSTAMP(13); // grants
         if (Gr > 0 && ns > 0) __syncthreads(); // S6: the grants are in the records before the next pass reads them
         LSTAMP(14);
-        if (scal[S_STATUS] != PRACH_OK) { status = scal[S_STATUS]; time_exit = t; break; }
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
         if (++t5 == 5) t5 = 0;
         if (++tA == aT) { tA = 0; slotA++; }
     }
     __syncthreads();
+    if (status == PRACH_OK && scal[S_STATUS] != PRACH_OK) status = scal[S_STATUS]; // (raised behind the last S3)
     if (pendN >= 0 && status == PRACH_OK) { calls(pendFa, pendN, false); pendN = -1; }
     __syncthreads();
 
