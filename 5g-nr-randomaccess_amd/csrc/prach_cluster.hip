@@ -57,6 +57,9 @@ namespace {
 constexpr int EVC_CALLER = 1, EVC_RESETCAND = 2, EVC_RJOIN = 3, EVC_LEAVER = 4;
 constexpr int EVCAPC = 4096; // gathered events per subframe held in LDS
 constexpr int SCAPC = 2048;  // singleton callers per subframe held in LDS
+#ifndef PRACH_PFD
+#define PRACH_PFD 4 // record slots of the streaming pass (compact_phase_a)
+#endif
 constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups): one run of DEADW / NW words per wavefront, see dead_skip
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
@@ -708,25 +711,29 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         }
     };
     int nvisit = 0;
-    // two record slots, refilled alternately: the next group's record is in flight while one is worked on
-    int j0 = next_live(w);
-    int j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
-    int4 r0 = fetch(j0), r1 = fetch(j1);
+    // PFD record slots, refilled round-robin: the records of the next PFD - 1 live groups are in flight while one is worked on.  With one
+    // workgroup per trial the pass streams from HBM (1000 trials x 5 MB) and Little's law is the bound: 16 wavefronts x (PFD - 1) x 512 B
+    // in flight per CU against a loaded latency of 1-2 us; with a cluster the records come from L2 and two slots are enough.
+    constexpr int PFD = CX::H8 ? PRACH_PFD : 2;
+    int jq[PFD];
+    int4 rq[PFD];
+    jq[0] = next_live(w);
+    rq[0] = fetch(jq[0]);
+#pragma unroll
+    for (int d = 1; d < PFD; d++) { jq[d] = jq[d - 1] >= 0 ? next_live(jq[d - 1] + NW) : -1; rq[d] = fetch(jq[d]); }
     bool hooked = false; // late_hook runs once: after this wavefront's first two groups, or at the end if it has fewer
-    for (;;) {
-        if (j0 < 0) break;
-        const int ja = j0;
-        const int4 ra = r0;
-        j0 = j1 >= 0 ? next_live(j1 + NW) : -1;
-        r0 = fetch(j0);
-        phase_a(ja, ra); nvisit++;
-        if (j1 < 0) break;
-        const int jb = j1;
-        const int4 rb = r1;
-        j1 = j0 >= 0 ? next_live(j0 + NW) : -1;
-        r1 = fetch(j1);
-        phase_a(jb, rb); nvisit++;
-        if (!hooked) { late_hook(); hooked = true; }
+    for (bool more = true; more;) {
+#pragma unroll
+        for (int d = 0; d < PFD; d++) {
+            if (jq[d] < 0) { more = false; break; }
+            const int ja = jq[d];
+            const int4 ra = rq[d];
+            const int jlast = jq[(d + PFD - 1) % PFD]; // the group fetched last
+            jq[d] = jlast >= 0 ? next_live(jlast + NW) : -1;
+            rq[d] = fetch(jq[d]);
+            phase_a(ja, ra); nvisit++;
+            if (d == 1 && !hooked) { late_hook(); hooked = true; }
+        }
     }
     if (!hooked) late_hook();
     if (lane == 0 && nvisit) atomicAdd(&L.scal[C_VISITS], nvisit); // (reported, never read by the simulation)
