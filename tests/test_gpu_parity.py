@@ -263,6 +263,34 @@ def test_several_clusters_in_one_launch(pkg, ob, engine):
         engine.set("cluster", 0)
 
 
+def test_xcd_packed_clusters(pkg, ob, engine):
+    """The lean cluster kernel's XCD-packed launch (a cluster on the blocks of equal blockIdx % 8, its granules resident in that XCD's L2
+    once the cluster has VERIFIED that it runs on one XCD) against the plain launch and the oracle: one cluster, eleven clusters (two
+    chunks of eight, the second one partly empty: blocks of trials past the last one leave at once), and a cluster size that cannot be
+    packed (64 workgroups > the CUs of an XCD: plain launch, same results).  prach_timing.xcd_packed reports what was launched."""
+    one = [pkg.make_cfg(30000, variant=0, rng_mode=pkg.RNG_PHILOX, seed=5)]
+    many = [pkg.make_cfg(n, variant=v, rng_mode=pkg.RNG_PHILOX, seed=s) for s, (n, v) in
+            enumerate([(9000, 0), (12000, 1), (7000, 0), (15000, 1), (5000, 0), (11000, 0), (8000, 1), (14000, 0), (6000, 1), (10000, 0), (13000, 1)])]
+    try:
+        for cfgs, G in ((one, 16), (many, 8), (one, 64)):
+            engine.set("cluster", G)
+            out = {}
+            for pack in (1, 0):
+                engine.set("xcd_pack", pack)
+                res, logs = engine.run_trials(cfgs, want_logs=True)
+                tm = engine.timing()
+                assert tm.rec_mode == 3 and tm.fallback_trials == 0 and tm.spin_timeouts == 0, (G, pack, tm.rec_mode)
+                assert tm.xcd_packed == (1 if pack and G <= 32 else 0), (G, pack, tm.xcd_packed)
+                out[pack] = ([r.as_dict() for r in res], [bytes(l) for l in logs])
+            assert out[0] == out[1], G
+            for c, r, l in zip(cfgs, *engine.run_trials(cfgs, want_logs=True)):
+                ores, oues = ob.run_trial(ob.make_cfg(c.nUE, variant=c.variant), ob.Rng(ob.RNG_PHILOX, int(c.seed)))
+                assert_same(pkg, r, l, ores, oues, ("packed", G, c.nUE))
+    finally:
+        engine.set("xcd_pack", 1)
+        engine.set("cluster", 0)
+
+
 def test_cluster_capacity_fallback_is_exact(pkg, ob, engine):
     """backoff 1 makes every retransmission land on the same subframe: thousands of special events per subframe
     exceed the cluster kernel's per-subframe LDS capacities; the engine reruns such trials on the
