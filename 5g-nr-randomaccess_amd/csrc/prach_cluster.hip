@@ -64,7 +64,7 @@ constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups): on
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 enum { C_NSUCC = 0, C_COLL, C_TXOP, C_CONTF, C_NS, C_NRC, C_NRJ, C_STATUS, C_NEV, C_NCAND, C_OVF, C_NSUCCTOT, C_NTOT,
-       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20, C_GTOT = 21, C_QN = 22, C_QEND = 23, C_VISITS = 24, C_EVENTS = 25 };
+       C_PTC, C_FC, C_SUMT = 16, C_ND = 18, C_NCROSS = 20, C_GTOT = 21, C_QN = 22, C_QEND = 23, C_VISITS = 24, C_EVENTS = 25, C_SX = 27 };
 
 struct CLds {
     int2 *gev;    // [EVCAPC] gathered events of all workgroups
@@ -211,6 +211,12 @@ __device__ __forceinline__ CLds ccarve(char *smem, bool glibc, int lslots) {
 // shared words: every access is a device-scope relaxed atomic == global_load/store ... sc1
 __device__ __forceinline__ long long ld_sc1_64(const PRACH_G long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1_64(PRACH_G long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// granule store of a cluster: write-through, or — once the cluster has VERIFIED that all its workgroups run on one XCD (handshake in the
+// kernel prologue, as in prach_lcluster.hip) — resident in that XCD's L2, where the peers' sc1 loads find it an L2 round trip later
+__device__ __forceinline__ void st_gr(const bool same_xcd, PRACH_G long long *p, long long v) {
+    if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct FastMods { FastMod nP, backoff, aT, five; };
 
@@ -254,6 +260,7 @@ struct CtxT {
     static constexpr bool H8 = REC_ == REC_H8;   // 8 + 4 byte hot record (one workgroup per trial, streaming)
     static constexpr bool LREC = REC_ == REC_L16; // LDS-resident records
     int b, G, evw, mbstride;
+    bool sx;             // the cluster shares one XCD (verified): granules stay in its L2
     FastMod fmG;         // LREC: slot of an owned UE = ((idx >> 6) - b) / G * 64 + (idx & 63)
     int4 *lrec;          // LREC: [lslots]
     unsigned *lnd;       // LREC: [lslots] Philox draw index
@@ -538,7 +545,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
                 const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
                 const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
                 if (C.G == 1) { if (slot < CX::EVCX) L.gev[slot] = make_int2(i, info); }
-                else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)i, (unsigned)info, tag));
+                else if (slot < C.evw) st_gr(C.sx, mbev + slot, mk_granule((unsigned)i, (unsigned)info, tag));
             }
         }
         const unsigned long long cm = __ballot(eclass);
@@ -848,7 +855,7 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fca
 
 // ---------------------------------------------------------------------------------------------
 template <bool GLIBC, int REC, bool SMALL>
-__global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(const TrialDev *__restrict__ params, const int Garg, const int lslots) {
+__global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(const TrialDev *__restrict__ params, const int Garg, const int lslots, const int xpack, const int ntrials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPC = SMALL ? NPC_S : NPC_G, QCAP = SMALL ? QCAP_S : QCAP_G, EVCAPC = SMALL ? EVC_S : EVCAPC_G;
     using LO = LdsOff<NPC, QCAP, EVCAPC>;
@@ -858,7 +865,12 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
     const int G = REC == REC_H8 ? 1 : Garg;
     // the workgroups of a cluster are CONSECUTIVE blocks: in-order dispatch completes whole clusters even when not every
     // block of the grid is resident at once (the engine keeps G x trials within the occupancy query's answer anyway)
-    const int T = blockIdx.x / G, b = blockIdx.x % G;
+    int T = blockIdx.x / G, b = blockIdx.x % G;
+    if (REC != REC_H8 && xpack) { // XCD-packed launch (prach_lcluster.hip): a cluster = the blocks of equal blockIdx % 8 of a chunk of 8 G blocks
+        const int chunk = blockIdx.x / (8 * G), within = blockIdx.x % (8 * G);
+        T = chunk * 8 + (within & 7); b = within >> 3;
+        if (T >= ntrials) return;
+    }
     const TrialG P(params[T]);
     const CLds L = ccarve<LO>(smem, GLIBC, REC == REC_L16 ? lslots : 0);
     const int tid = threadIdx.x;
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
     FastMods FM;
     FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
     CtxT<REC, SMALL> C;
-    C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox;
+    C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox; C.sx = false;
     C.fmG = make_fastmod(G); C.lrec = L.lrec; C.lnd = L.lnd; C.lcand = L.lcand;
     C.status_word = &L.scal[C_STATUS];
     C.rec = P.rec;
@@ -897,10 +909,26 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
     for (int k = tid; k < DEADW; k += WG_THREADS) L.dead[k] = 0;
     if (GLIBC) for (int k = tid; k < GSCAP; k += WG_THREADS) { L.gsum[k] = 0; L.gpre[k] = 0; }
     __syncthreads();
+    if (REC != REC_H8 && xpack && G > 1 && G <= 64) {
+        // same-XCD handshake (prach_lcluster.hip): every workgroup publishes the XCD it runs on (write-through granule, tag 0xFFFF, header of
+        // its parity-1 mailbox: first used by subframe 1, which nobody reaches before every peer is past this point) and reads all G
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xfu;
+        if (tid == 0) st_sc1_64(gr_of(C, 1, b), mk_granule(xcc, 0u, 0xFFFFu));
+        if (tid < 64) {
+            bool same = true;
+            if (tid < G) same = ((unsigned)wait_granule(gr_of(C, 1, tid), 0xFFFFu, &L.scal[C_STATUS]) & 0xFFFFFu) == xcc;
+            const bool all = __ballot(!same) == 0ull;
+            if (tid == 0) L.scal[C_SX] = all ? 1 : 0;
+        }
+        __syncthreads();
+        C.sx = L.scal[C_SX] != 0 && L.scal[C_STATUS] == PRACH_OK;
+    }
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = P.stop;
     unsigned long long steps = 0;
-    int status = (lgroups > DEADW * 32 || (GLIBC && totgroups > GSCAP) || (REC == REC_L16 && (lgroups * 64 > lslots || lslots > LQCAP)) || nP > NPC) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (lgroups > DEADW * 32 || (GLIBC && totgroups > GSCAP) || (REC == REC_L16 && (lgroups * 64 > lslots || lslots > LQCAP)) || nP > NPC || P.stop >= 0xFFFE) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
     unsigned long long base = 0; // glibc: rand() calls consumed so far (relative to the stream window)
 #ifdef PRACH_STAMPS
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -978,7 +1006,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
                 PRACH_G long long *const mine = mygr + 1 + nP + C.evw;
                 for (int q = tid; q < nq; q += WG_THREADS) {
                     const int g0 = b + G * (2 * q), g1 = b + G * (2 * q + 1);
-                    st_sc1_64(mine + q, mk_granule(g0 < totgroups ? (unsigned)L.gsum[g0] : 0u, g1 < totgroups ? (unsigned)L.gsum[g1] : 0u, tag));
+                    st_gr(C.sx, mine + q, mk_granule(g0 < totgroups ? (unsigned)L.gsum[g0] : 0u, g1 < totgroups ? (unsigned)L.gsum[g1] : 0u, tag));
                 }
                 for (int k = tid; k < G * nq; k += WG_THREADS) {
                     const int wg = k / nq, q = k - wg * nq;
@@ -1038,7 +1066,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
                 const int slot = atomicAdd(&L.scal[C_NEV], 1);
                 const int info = EVC_LEAVER | (c.y << 4);
                 if (G == 1) { if (slot < EVCAPC) L.gev[slot] = make_int2(c.x, info); }
-                else if (slot < C.evw) st_sc1_64(mbev + slot, mk_granule((unsigned)c.x, (unsigned)info, tag));
+                else if (slot < C.evw) st_gr(C.sx, mbev + slot, mk_granule((unsigned)c.x, (unsigned)info, tag));
             }
         }
         for (int k = tid; k < nP; k += WG_THREADS) { fcallB[k] = INT_MAX; lcallB[k] = -1; L.total[k] = 0; L.nlv[k] = 0; L.fie[k] = 0; } // ready for the gathers
@@ -1068,11 +1096,11 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
             // publish: per bucket {histogram, lowest caller}, header {#events, overflow, #successes}: self-validating granules
             for (int k = tid; k < nP; k += WG_THREADS) {
                 const int ml = min(Lc.mloc[k], Lc.mloc_stay[k]);
-                st_sc1_64(mygr + 1 + k, mk_granule((unsigned)Lc.hist[k], ml == INT_MAX ? GR_NONE : (unsigned)ml, tag));
+                st_gr(C.sx, mygr + 1 + k, mk_granule((unsigned)Lc.hist[k], ml == INT_MAX ? GR_NONE : (unsigned)ml, tag));
             }
             if (tid == 0) {
                 const int nevraw = L.scal[C_NEV];
-                st_sc1_64(mygr, mk_granule((unsigned)min(nevraw, C.evw) | (nevraw > C.evw ? (1u << 13) : 0u), (unsigned)L.scal[C_NSUCC], tag));
+                st_gr(C.sx, mygr, mk_granule((unsigned)min(nevraw, C.evw) | (nevraw > C.evw ? (1u << 13) : 0u), (unsigned)L.scal[C_NSUCC], tag));
                 L.scal[C_NEV] = 0; L.scal[C_NCAND] = 0;
             }
             STAMP(1);
@@ -1363,7 +1391,7 @@ size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small) {
 }
 int cluster_small_max_preambles() { return NPC_S; }
 
-using cluster_kernel_t = void (*)(const TrialDev *, int, int);
+using cluster_kernel_t = void (*)(const TrialDev *, int, int, int, int);
 // rec_mode: REC_G16 / REC_H8 (one workgroup per trial: the streaming regime) / REC_L16 (clusters, Philox: LDS-resident records)
 static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode, bool small) {
     if (rng_mode == PRACH_RNG_GLIBC) return rec_mode == REC_H8 ? cluster_kernel<true, REC_H8, false> : cluster_kernel<true, REC_G16, false>;
@@ -1371,14 +1399,16 @@ static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode, bool sma
     return rec_mode == REC_L16 ? cluster_kernel<false, REC_L16, false> : (rec_mode == REC_H8 ? cluster_kernel<false, REC_H8, false> : cluster_kernel<false, REC_G16, false>);
 }
 
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, hipStream_t stream) {
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, int xpack, hipStream_t stream) {
     if (rec_mode != REC_L16) lslots = 0;
     small = small && rec_mode == REC_H8 && rng_mode != PRACH_RNG_GLIBC;
     const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, small);
     const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode, small);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(fn, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, lslots);
+    if (rec_mode == REC_H8 || G <= 1) xpack = 0;
+    const int grid = xpack ? ((ntrials + 7) / 8) * 8 * G : ntrials * G;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(WG_THREADS), lds, stream, params, G, lslots, xpack, ntrials);
     return hipGetLastError();
 }
 

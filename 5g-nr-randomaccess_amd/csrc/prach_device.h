@@ -100,7 +100,7 @@ hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, in
 int lcluster_kernel_blocks_per_cu(int lslots);
 constexpr int CLUSTER_LQCAP = 4096; // LDS-resident clusters: owned UE slots per workgroup at most (= the event queue)
 constexpr size_t CLUSTER_LDS_LIMIT = 160 * 1024; // LDS per CU (MI355X_MICROARCH.md): one LDS-resident cluster workgroup per CU
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, hipStream_t stream);
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, int xpack, hipStream_t stream);
 int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots); // occupancy query for the kernel and its dynamic LDS size
 constexpr int STREAM_CHUNK = 31 * 2048; // rand() outputs generated per wavefront (prach_stream.hip)
 hipError_t launch_glibc_stream(const unsigned *seeds, int *out, unsigned long long n, hipStream_t stream);

@@ -369,17 +369,15 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         const int lslots = lds_record_slots(e, cfgs, idx, m, G, maxP);
         const int rec_mode = use_fast_kernel(e, lslots, maxP) ? CLUSTER_REC_LFAST : (lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16));
         e->last.rec_mode = rec_mode;
-        if (rec_mode == CLUSTER_REC_LFAST) {
-            // XCD-packed launch (prach_lcluster.hip): each cluster on one XCD, eight clusters side by side — when the clusters of the
-            // launch fit the XCDs' CUs that way (one workgroup per CU: the LDS-resident state fills it)
-            const int xpack = e->opt_xcd_pack && !e->pack_off && G > 1 && ((m + 7) / 8) * G <= e->num_cus / 8;
-            e->last.xcd_packed = xpack;
-            HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, xpack, e->stream));
-        }
+        // XCD-packed launch (prach_lcluster.hip): each cluster on one XCD, eight clusters side by side — when the clusters of the launch fit
+        // the XCDs' CUs that way (budgeted at one workgroup per CU: LDS-resident state fills a CU, the general layouts take more than half)
+        const int xpack = e->opt_xcd_pack && !e->pack_off && G > 1 && rec_mode != CLUSTER_REC_H8 && ((m + 7) / 8) * G <= e->num_cus / 8;
+        e->last.xcd_packed = xpack;
+        if (rec_mode == CLUSTER_REC_LFAST) HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, xpack, e->stream));
         else {
             // the streaming layout (two 1024-thread workgroups = two independent trials per CU): one workgroup per trial, Philox, <= 64 preambles
             const int small = rec_mode == CLUSTER_REC_H8 && rng_mode == PRACH_RNG_PHILOX && maxP <= cluster_small_max_preambles() && e->opt_two_per_cu;
-            HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, small, e->stream));
+            HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, small, xpack, e->stream));
         }
     }
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(A), m, rng_mode, maxP, e->stream));
