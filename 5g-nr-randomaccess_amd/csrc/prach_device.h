@@ -108,7 +108,7 @@ extern "C" void prach_internal_glibc_seeds(uint32_t seed, uint64_t first, uint64
 constexpr int CLUSTER_GLIBC_MAX_UE = 4096 * 64; // glibc mode on the cluster kernel: per-group draw counts live in LDS
 constexpr int CLUSTER_MAX_G = 64;
 size_t noma_kernel_lds_bytes(int nP);
-hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream);
+hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, int xpack, hipStream_t stream);
 int noma_kernel_blocks_per_cu(int maxP);
 // NOMA_C in the reference's own rand() stream (prach_noma_glibc.hip): one trial, host-activated arrivals + one device step per access slot
 int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *hstream, unsigned long long len, prach_result *res, prach_ue_log *logs,

@@ -357,7 +357,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         for (int k = 0; k < m; k++)
             HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(A + LL.t[k].seeds), reinterpret_cast<int *>(A + LL.t[k].stream),
                                        (unsigned long long)LL.t[k].stream_len, e->stream));
-    if (noma) HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, e->stream));
+    if (noma) {
+        const int xpack = e->opt_xcd_pack && !e->pack_off && G > 1 && ((m + 7) / 8) * G <= e->num_cus / 8;
+        e->last.xcd_packed = xpack;
+        HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, xpack, e->stream));
+    }
     else if (G > 0) {
         // one workgroup per trial = the streaming regime: 8 + 4 byte hot records, if every subframe number of every trial of
         // the launch fits 16 bits (txTime <= t + 59 + backoff + accessTime)

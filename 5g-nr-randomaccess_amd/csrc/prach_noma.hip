@@ -48,7 +48,7 @@ struct NLds {
     double *slg; // [6*64] ln(gain)
     int *scal;   // [32]
 };
-enum { N_NSUCC = 0, N_STATUS, N_PTC, N_FC, N_MAXT, N_NSUCCTOT, N_MAXTTOT, N_PAIRD, N_SUMT = 8, N_ND = 10 };
+enum { N_NSUCC = 0, N_STATUS, N_PTC, N_FC, N_MAXT, N_NSUCCTOT, N_MAXTTOT, N_PAIRD, N_SUMT = 8, N_ND = 10, N_SX = 12 };
 
 __device__ __forceinline__ NLds ncarve(char *smem, int nP) {
     NLds L;
@@ -66,6 +66,11 @@ __device__ __forceinline__ NLds ncarve(char *smem, int nP) {
 
 __device__ __forceinline__ long long nld(const PRACH_G long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void nst(PRACH_G long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... or, for a cluster that has verified that it runs on one XCD (prologue handshake, as in prach_lcluster.hip), resident in that XCD's L2
+__device__ __forceinline__ void nstx(const bool same_xcd, PRACH_G long long *p, long long v) {
+    if (same_xcd) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ long long nmk(unsigned lo20, unsigned hi20, unsigned tag) {
     const unsigned w0 = (lo20 & 0xFFFFFu) | ((tag & 0xFFFu) << 20), w1 = (hi20 & 0xFFFFFu) | (((tag >> 12) & 0xFu) << 20);
     return (long long)(((unsigned long long)w1 << 32) | w0);
@@ -89,10 +94,14 @@ __device__ __forceinline__ long long nwait(const PRACH_G long long *p, unsigned 
 
 size_t noma_kernel_lds_bytes(int nP) { return sizeof(double) * 2 * 6 * 64 + sizeof(int) * (6 * 64 + 32 + 4 * 6 * nP); }
 
-__global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__restrict__ params, const int G, const int nT) {
+__global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__restrict__ params, const int G, const int nT, const int xpack) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
-    (void)nT;
+    int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
+    if (xpack) { // XCD-packed launch (prach_lcluster.hip): a cluster = the blocks of equal blockIdx % 8 of a chunk of 8 G blocks
+        const int chunk = blockIdx.x / (8 * G), within = blockIdx.x % (8 * G);
+        T = chunk * 8 + (within & 7); b = within >> 3;
+        if (T >= nT) return;
+    }
     const TrialG P(params[T]);
     const NLds L = ncarve(smem, P.nP);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -116,6 +125,22 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     __syncthreads();
     if (tid == 0) L.scal[N_MAXT] = -1;
     __syncthreads();
+    bool sx = false;
+    if (xpack && G > 1 && G <= 64) { // same-XCD handshake: XCC ids through write-through granules (tag 0xFFFF, header of the parity-1 mailbox)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xfu;
+        PRACH_G long long *const hs = mbox + (size_t)G * mbstride;
+        if (tid == 0) nst(hs + (size_t)b * mbstride, nmk(xcc, 0u, 0xFFFFu));
+        if (tid < 64) {
+            bool same = true;
+            if (tid < G) same = ((unsigned)nwait(hs + (size_t)tid * mbstride, 0xFFFFu, &L.scal[N_STATUS]) & 0xFFFFFu) == xcc;
+            const bool all = __ballot(!same) == 0ull;
+            if (tid == 0) L.scal[N_SX] = all ? 1 : 0;
+        }
+        __syncthreads();
+        sx = L.scal[N_SX] != 0 && L.scal[N_STATUS] == PRACH_OK;
+    }
 
     int activeCheck = 0, time_exit = P.stop, status = PRACH_OK;
     bool all_done = false;
@@ -177,10 +202,10 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             PRACH_G long long *const mygr = mbox + ((size_t)(s & 1) * G + b) * mbstride;
             for (int k = tid; k < nb; k += WG_THREADS) {
                 const int wv = L.who[k];
-                nst(mygr + 1 + k, nmk((unsigned)L.cnt[k], wv == INT_MAX ? NGR_NONE : (unsigned)wv, tag));
+                nstx(sx, mygr + 1 + k, nmk((unsigned)L.cnt[k], wv == INT_MAX ? NGR_NONE : (unsigned)wv, tag));
                 L.cnt[k] = 0; L.who[k] = INT_MAX; // the next slot's gather starts in this slot's pass B
             }
-            if (tid == 0) nst(mygr, nmk((unsigned)L.scal[N_NSUCC], (unsigned)(L.scal[N_MAXT] + 1), tag));
+            if (tid == 0) nstx(sx, mygr, nmk((unsigned)L.scal[N_NSUCC], (unsigned)(L.scal[N_MAXT] + 1), tag));
             for (int k0 = tid; k0 < G * nb; k0 += 4 * WG_THREADS) { // four granule loads in flight per thread
                 long long gv[4];
                 int kk[4];
@@ -455,11 +480,13 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     }
 }
 
-hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, hipStream_t stream) {
+hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, int xpack, hipStream_t stream) {
     const size_t lds = noma_kernel_lds_bytes(maxP);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&noma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(noma_kernel, dim3(ntrials * G), dim3(WG_THREADS), lds, stream, params, G, ntrials);
+    if (G <= 1) xpack = 0;
+    const int grid = xpack ? ((ntrials + 7) / 8) * 8 * G : ntrials * G;
+    hipLaunchKernelGGL(noma_kernel, dim3(grid), dim3(WG_THREADS), lds, stream, params, G, ntrials, xpack);
     return hipGetLastError();
 }
 
