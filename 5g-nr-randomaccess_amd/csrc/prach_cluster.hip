@@ -80,6 +80,7 @@ struct CLds {
                                // candidates per bucket of this workgroup
     int *total, *fcall, *lcall, *nlv, *fie; // [nP] each ([2][nP]: fcall, lcall)
     int *queue;   // [QCAP] Philox pass: UEs of this workgroup that have an event in this subframe
+    int *stage;   // [NW][stage entries] global-record kernels: what a wavefront collects before it takes queue slots (compact_phase_a)
     int *gsum;    // [GSCAP] glibc mode: rand() calls of every 64-UE group in this subframe's UE loop
     int *gpre;    // [GSCAP] their exclusive prefix in index order
     unsigned *gmask; // [4 * GSCAP / 2] compacted glibc pass: per OWN group, lanes that draw once or twice (2 words) / twice (2 words)
@@ -150,7 +151,7 @@ constexpr int LQCAP = CLUSTER_LQCAP; // LDS-resident clusters: event queue = at 
 // Two layouts: the general one (bucket stride 256, QCAP-entry queue) and the SMALL one of the streaming regime (one workgroup per
 // trial, nPreamble <= 64: bucket stride 64, half the queue, half the gathered-event list) — 61 KB instead of 97 KB, so that TWO
 // 1024-thread workgroups (two independent trials) share a CU: 8 wavefronts per SIMD instead of 4.
-template <int NPC_, int QCAP_, int EVC_>
+template <int NPC_, int QCAP_, int EVC_, int STG_>
 struct LdsOff {
     static constexpr int GEV = 0;
     static constexpr int SIDX = GEV + 8 * EVC_;
@@ -170,15 +171,18 @@ struct LdsOff {
     static constexpr int NLV = LCALL + 4 * 2 * NPC_;
     static constexpr int FIE = NLV + 4 * NPC_;
     static constexpr int QUEUE = FIE + 4 * NPC_;
-    static constexpr int TAIL_G = QUEUE + 4 * QCAP_;  // global-record kernels: (glibc) gsum, gpre, gmask follow the QCAP-entry queue
+    static constexpr int STAGE = QUEUE + 4 * QCAP_;   // global-record kernels: [NW][STG_] per-wavefront stage of the compacted pass (compact_phase_a)
+    static constexpr int TAIL_G = STAGE + 4 * NW * STG_; // ... then (glibc) gsum, gpre, gmask
     static constexpr int LCAND = QUEUE + 4 * LQCAP;  // LDS-resident kernels: LQCAP-entry queue, candidate list, then the launch-sized tail
     static constexpr int TAIL_L = LCAND + 8 * LCANDCAP;
     static_assert(SIDX % 16 == 0 && TAIL_L % 16 == 0, "16-byte alignment of the event and record arrays");
 };
 constexpr int NPC_S = 64, QCAP_S = QCAP < 4096 ? QCAP : 4096, EVC_S = 2048; // the small layout
 constexpr int NPC_G = NPC, QCAP_G = QCAP, EVCAPC_G = EVCAPC; // (the kernel shadows the three names with its layout's values)
-using lds_off = LdsOff<NPC, QCAP, EVCAPC>;
-using lds_off_s = LdsOff<NPC_S, QCAP_S, EVC_S>;
+// stage entries per wavefront: 64 left over from the round before + 64 per record slot of a round (PRACH_PFD slots; the small layout: 2)
+template <int REC_, bool SMALL_, bool GLIBC_> struct CtxT;
+using lds_off = LdsOff<NPC, QCAP, EVCAPC, 0>;      // (offsets in front of the stage do not depend on it)
+using lds_off_s = LdsOff<NPC_S, QCAP_S, EVC_S, 64 + 64 * 2>;
 static_assert(lds_off_s::TAIL_G <= 80 * 1024, "two workgroups of the small layout per CU");
 
 template <class O>
@@ -197,6 +201,7 @@ __device__ __forceinline__ CLds ccarve(char *smem, bool glibc, int lslots) {
     L.total = reinterpret_cast<int *>(smem + O::TOTAL); L.fcall = reinterpret_cast<int *>(smem + O::FCALL);
     L.lcall = reinterpret_cast<int *>(smem + O::LCALL); L.nlv = reinterpret_cast<int *>(smem + O::NLV); L.fie = reinterpret_cast<int *>(smem + O::FIE);
     L.queue = reinterpret_cast<int *>(smem + O::QUEUE);
+    L.stage = reinterpret_cast<int *>(smem + O::STAGE); // (the LDS-resident layouts overlay this space and never use it)
     L.gsum = reinterpret_cast<int *>(smem + O::TAIL_G); L.gpre = L.gsum + GSCAP; L.gmask = reinterpret_cast<unsigned *>(L.gsum + 2 * GSCAP); // only touched in glibc mode
     (void)glibc;
     L.lrec = nullptr; L.lnd = nullptr; L.lcand = nullptr;
@@ -252,13 +257,18 @@ __device__ __forceinline__ long long wait_granule(const PRACH_G long long *p, un
 //            whole trial (49 groups x 64 UEs x 20 bytes = 63 KB at nUE = 100 000, G = 32): the pass, the event body and the grant
 //            never touch L2 for a record; global memory only sees the cold per-UE fields and the final state
 constexpr int REC_G16 = 0, REC_H8 = 1, REC_L16 = 2;
-template <int REC_, bool SMALL_ = false>
+template <int REC_, bool SMALL_ = false, bool GLIBC_ = false>
 struct CtxT {
     static constexpr int REC = REC_;
     static constexpr int QCAPX = SMALL_ ? QCAP_S : QCAP;     // event queue entries
     static constexpr int EVCX = SMALL_ ? EVC_S : EVCAPC;      // gathered events held in LDS
     static constexpr bool H8 = REC_ == REC_H8;   // 8 + 4 byte hot record (one workgroup per trial, streaming)
     static constexpr bool LREC = REC_ == REC_L16; // LDS-resident records
+    static constexpr int PFD = (REC_ == REC_H8 && !SMALL_ && !GLIBC_) ? PRACH_PFD : 2; // record slots of the compacted pass's walk
+    // the compacted pass collects its event UEs on a per-wavefront stage (64 + 64 per record slot) before it takes queue slots for them —
+    // where LDS has room for it: not beside LDS-resident records, not beside the glibc modes' 64 KB of group sums (158.6 of 160 KB already)
+    static constexpr bool STAGED = REC_ != REC_L16 && !GLIBC_;
+    static constexpr int STG = STAGED ? 64 + 64 * PFD : 0;
     int b, G, evw, mbstride;
     bool sx;             // the cluster shares one XCD (verified): granules stay in its L2
     FastMod fmG;         // LREC: slot of an owned UE = ((idx >> 6) - b) / G * 64 + (idx & 63)
@@ -662,6 +672,9 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         return hot_load_pass(C, min((unsigned)((C.b + C.G * jj) * 64 + lane), lastrec), max(jj, 0) * 64 + lane);
     };
     const unsigned rarlim = (unsigned)(maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
+    constexpr bool STAGED = CX::STAGED;
+    int *const stage = L.stage + w * CX::STG;
+    int sc = 0; // staged UEs of this wavefront (wave-uniform)
     // ---- phase A ----
     auto phase_a = [&](const int j, const int4 r) __attribute__((always_inline)) {
         const int g = C.b + C.G * j;
@@ -700,28 +713,58 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
         }
         const unsigned long long hm = mHeavy;
         if (hm) {
-            const int n = __builtin_amdgcn_readfirstlane(__popcll(hm)); // (said to be uniform: the atomic below then needs no per-lane scan)
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&L.scal[C_QN], n);
-            base = __builtin_amdgcn_readlane(base, 0);
-            if (CX::LREC || base + n <= CX::QCAPX) { // (LDS-resident: the queue holds slots and has room for every owned UE)
-                if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = CX::LREC ? j * 64 + lane : i;
-            } else if (SPEC) { // cannot happen: the kernel runs ahead only if every owned UE fits the queue
-                if (lane == 0) L.scal[C_STATUS] = PRACH_ERR_INTERNAL;
-            } else { // queue full: this wavefront does its events in place
-                if (lane == 0) atomicMin(&L.scal[C_QEND], base);
-                unsigned ndc = 0;
-                int4 rf = make_int4(-1, 0, 0, 0);
-                if (heavy) { ndc = P.nd[i]; rf = CX::H8 ? make_int4(r.x, C.tbase[(unsigned)i], r.z, r.w) : r; }
-                ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, g, -1, i, 0, heavy, rf, ndc, c_succ, c_contf);
+            const int n = __builtin_amdgcn_readfirstlane(__popcll(hm));
+            if (STAGED) { // global records: onto this wavefront's stage (the walk keeps room for a whole group in front of every round)
+                if (heavy) stage[sc + __popcll(hm & lanemask_lt(lane))] = i;
+                sc += n;
+            } else {      // no stage: queue slots per visit
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&L.scal[C_QN], n);
+                base = __builtin_amdgcn_readlane(base, 0);
+                if (CX::LREC || base + n <= CX::QCAPX) { // (LDS-resident: the queue holds slots and has room for every owned UE)
+                    if (heavy) L.queue[base + __popcll(hm & lanemask_lt(lane))] = CX::LREC ? j * 64 + lane : i;
+                } else if (SPEC) { // cannot happen: the kernel runs ahead only if every owned UE fits the queue
+                    if (lane == 0) L.scal[C_STATUS] = PRACH_ERR_INTERNAL;
+                } else { // queue full: this wavefront does its events in place
+                    if (lane == 0) atomicMin(&L.scal[C_QEND], base);
+                    unsigned ndc = 0;
+                    int4 rf = make_int4(-1, 0, 0, 0);
+                    if (heavy) { ndc = P.nd[i]; rf = CX::H8 ? make_int4(r.x, C.tbase[(unsigned)i], r.z, r.w) : r; }
+                    ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, g, -1, i, 0, heavy, rf, ndc, c_succ, c_contf);
+                }
             }
         }
+    };
+    // The stage goes to the workgroup's event queue in one piece — one returning LDS atomic per ~100 event UEs instead of one per group
+    // visit: the slot allocation was a quarter of a visit's instructions, in a pass bound by instruction issue.  Queue full (the peak of
+    // an overloaded 100 000-UE trial on one workgroup): this wavefront runs the full body on its staged UEs right here, gathered by index
+    // as phase B would — ONE inlined copy of the body, outside the unrolled walk (it used to sit inside every record slot).
+    auto flush = [&]() __attribute__((always_inline)) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&L.scal[C_QN], sc);
+        base = __builtin_amdgcn_readlane(base, 0);
+        const bool room = base + sc <= CX::QCAPX;
+        if (!room && !SPEC && lane == 0) atomicMin(&L.scal[C_QEND], base);
+        if (!room && SPEC && lane == 0) L.scal[C_STATUS] = PRACH_ERR_INTERNAL; // cannot happen: the kernel runs ahead only if every owned UE fits the queue
+        for (int o = 0; o < sc; o += 64) {
+            const bool v = o + lane < sc;
+            const int qe = v ? stage[o + lane] : 0;
+            if (room) { if (v) L.queue[base + o + lane] = qe; }
+            else if (!SPEC) {
+                int4 rf = make_int4(-1, 0, 0, 0);
+                unsigned ndc = 0;
+                if (v) { rf = hot_load_full(C, qe, 0); ndc = nd_load(P, C, qe, 0); }
+                ue_step<0>(P, L, C, FM, fcall, lcall, t, prevAC, mbev, tag, 0ull, lane, qe >> 6, -1, qe, 0, v, rf, ndc, c_succ, c_contf);
+            }
+        }
+        sc = 0;
     };
     int nvisit = 0;
     // PFD record slots, refilled round-robin: the records of the next PFD - 1 live groups are in flight while one is worked on.  With one
     // workgroup per trial the pass streams from HBM (1000 trials x 5 MB) and Little's law is the bound: 16 wavefronts x (PFD - 1) x 512 B
     // in flight per CU against a loaded latency of 1-2 us; with a cluster the records come from L2 and two slots are enough.
-    constexpr int PFD = CX::H8 ? PRACH_PFD : 2;
+    constexpr int PFD = CX::PFD;
+    static_assert(!STAGED || CX::STG >= 64 + 64 * PFD, "a round of the walk fits the stage behind a leftover of at most 64");
     int jq[PFD];
     int4 rq[PFD];
     jq[0] = next_live(w);
@@ -729,7 +772,9 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
 #pragma unroll
     for (int d = 1; d < PFD; d++) { jq[d] = jq[d - 1] >= 0 ? next_live(jq[d - 1] + NW) : -1; rq[d] = fetch(jq[d]); }
     bool hooked = false; // late_hook runs once: after this wavefront's first two groups, or at the end if it has fewer
-    for (bool more = true; more;) {
+    for (bool more = true;;) {
+        if (STAGED && sc > 0 && (sc > 64 || !more)) flush(); // (the ONE place the stage is emptied)
+        if (!more) break;
 #pragma unroll
         for (int d = 0; d < PFD; d++) {
             if (jq[d] < 0) { more = false; break; }
@@ -858,7 +903,7 @@ template <bool GLIBC, int REC, bool SMALL>
 __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(const TrialDev *__restrict__ params, const int Garg, const int lslots, const int xpack, const int ntrials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPC = SMALL ? NPC_S : NPC_G, QCAP = SMALL ? QCAP_S : QCAP_G, EVCAPC = SMALL ? EVC_S : EVCAPC_G;
-    using LO = LdsOff<NPC, QCAP, EVCAPC>;
+    using LO = LdsOff<NPC, QCAP, EVCAPC, CtxT<REC, SMALL, GLIBC>::STG>;
     // the 8 + 4 byte record form is only ever launched with ONE workgroup per trial (the streaming regime): there the cluster size is a
     // compile-time 1 and every exchange / mailbox / pipeline path of this kernel is dead code the compiler drops (half the code, fewer
     // live scalars in the pass)
@@ -879,7 +924,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
 
     FastMods FM;
     FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
-    CtxT<REC, SMALL> C;
+    CtxT<REC, SMALL, GLIBC> C;
     C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox; C.sx = false;
     C.fmG = make_fastmod(G); C.lrec = L.lrec; C.lnd = L.lnd; C.lcand = L.lcand;
     C.status_word = &L.scal[C_STATUS];
@@ -1383,11 +1428,12 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
 }
 
 // small: the streaming layout (one workgroup per trial, Philox, nPreamble <= 64): two workgroups per CU
-size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small) {
+size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small, int rec_mode) {
     (void)nP; // the per-bucket tables have a fixed stride
     if (small) return (size_t)lds_off_s::TAIL_G;
     if (lslots > 0) return (size_t)lds_off::TAIL_L + (size_t)lslots * 20;
-    return (size_t)lds_off::TAIL_G + (glibc ? sizeof(int) * 4 * GSCAP : 0);
+    if (glibc) return (size_t)lds_off::TAIL_G + sizeof(int) * 4 * GSCAP; // (no stage: CtxT::STAGED)
+    return (size_t)lds_off::TAIL_G + sizeof(int) * NW * (rec_mode == REC_H8 ? CtxT<REC_H8, false, false>::STG : CtxT<REC_G16, false, false>::STG);
 }
 int cluster_small_max_preambles() { return NPC_S; }
 
@@ -1402,7 +1448,7 @@ static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode, bool sma
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, int xpack, hipStream_t stream) {
     if (rec_mode != REC_L16) lslots = 0;
     small = small && rec_mode == REC_H8 && rng_mode != PRACH_RNG_GLIBC;
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, small);
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, small, rec_mode);
     const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode, small);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
@@ -1415,7 +1461,7 @@ hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int
 // workgroups of this kernel (with its dynamic LDS) the runtime admits per CU: what a cooperative launch would be checked against
 int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots) {
     if (rec_mode != REC_L16) lslots = 0;
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, false);
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, false, rec_mode);
     const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode, false);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
     int nb = 0;

@@ -87,7 +87,7 @@ constexpr int RCCAP = 256;          // reset-cycle re-join candidates per subfra
 
 size_t trial_kernel_lds_bytes(int nP);
 hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream);
-size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small = false);
+size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small = false, int rec_mode = 0);
 int cluster_small_max_preambles(); // the streaming layout (two workgroups per CU) holds this many preambles
 // rec_mode: where / how a trial's hot records are kept (prach_cluster.hip): 0 global 16 B, 1 global 8 + 4 B (one workgroup per
 // trial), 2 LDS-resident (clusters, Philox; lslots = owned UE slots per workgroup, the launch's maximum)
