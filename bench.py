@@ -260,10 +260,10 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
                      "own_bytes_per_update": sum(owns) / max(1, updates_per_step * args.steps / world),
                      "dense_formulation_GBps_32B_per_update": ALGO_BYTES_PER_UPDATE * updates_per_step / world / (sum(kmss) / args.steps * 1e-3) / 1e9,
                      "note": "counter-measured HBM traffic of this regime (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes): profiles/r02_summary.md "
-                             "(config 3: 3.30 TB/s = 41 % of peak, 1.9x the own bytes: the event body's scattered 4- and 8-byte accesses move whole sectors)"},
+                             "(config 3: 3.58 TB/s = 45 % of peak, 1.9x the own bytes: the event body's scattered 4- and 8-byte accesses move whole sectors)"},
         # the N = 1 line of the driver's scaling run is the single-trial workload (configs[1]); the one-GPU figure of THIS workload, for the
         # strong-scaling efficiency of the grid, is the same command with `--gpus 1 --workload grid` (measured at the end of round 2)
-        "scaling_reference": {"n_gpus": 1, "workload": "this grid (--workload grid --times 1000)", "value": 7.69e11, "unit": "UE-subframe updates/s",
+        "scaling_reference": {"n_gpus": 1, "workload": "this grid (--workload grid --times 1000)", "value": 7.91e11, "unit": "UE-subframe updates/s",
                               "source": "DESIGN.md section 5 (one MI355X, end of round 2); rerun: python bench.py --gpus 1 --workload grid"},
         "success_ratio": {str(p): float(tot[k, fi["nSuccessUE"]]) / (args.times * p) for k, p in enumerate(points)},
         "results_csv_sha256": __import__("hashlib").sha256(csv_bytes).hexdigest(),
