@@ -667,11 +667,13 @@ __device__ __forceinline__ void compact_phase_a(const TrialG &P, const CLds &L, 
     auto next_live = [&](const int jj) -> int { return __builtin_amdgcn_readfirstlane(dead_skip(L, jj, C.b, C.G, ngroups, dc)); };
     // The prefetch is an unconditional load of an in-range record (lanes past the arrived UEs re-read the last one and
     // ignore it): nothing has to be merged with a default value, so nothing is waited for before the record is used.
-    const unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
+    unsigned lastrec = (unsigned)(max(activeCheck, 1) - 1);
+    asm volatile("" : "+v"(lastrec)); // (only ever a VALU operand: in a vector register it is not a spilled scalar reloaded by v_readlane per visit)
     auto fetch = [&](int jj) -> int4 { // H8: 8 bytes per UE, the timer base (.y) is not needed here
         return hot_load_pass(C, min((unsigned)((C.b + C.G * jj) * 64 + lane), lastrec), max(jj, 0) * 64 + lane);
     };
-    const unsigned rarlim = (unsigned)(maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
+    unsigned rarlim = (unsigned)(maxRar - 1) << PK_RAR_SHIFT; // window still open after this subframe: rar + 1 < maxRarWindow
+    asm volatile("" : "+v"(rarlim));
     constexpr bool STAGED = CX::STAGED;
     int *const stage = L.stage + w * CX::STG;
     int sc = 0; // staged UEs of this wavefront (wave-uniform)
