@@ -15,6 +15,11 @@
 //   * the hot record (16 B) and the Philox draw index of every owned UE live in LDS for the whole trial (no L2 round trip
 //     for a record, a draw index or an early-leaver candidate anywhere in the step loop); finished groups are a per-wavefront
 //     register bit mask; subframe bookkeeping (t mod 5, t mod accessTime, the arrival table) is incremental scalar state;
+//   * wavefront prefix sums / reductions run on the DPP network (wave_scan_incl, prach_device_fn.h), not through ds_bpermute round trips;
+//   * launched XCD-packed (a cluster = the blocks of equal blockIdx % 8), a cluster that has VERIFIED one common XCD keeps its exchange
+//     granules in that XCD's L2 (handshake in the prologue; any other placement keeps the write-through granules);
+//   * the last wavefront is the exchange's (bucket publish, headers, event offsets) and walks no UE groups; the header leaves right
+//     behind S1 when there is no early-leaver candidate (no barrier S2);
 //   * only the Philox path, only clusters (G > 1), only the pipelined compacted pass: the engine falls back to
 //     prach::cluster_kernel for everything else (glibc streams, one workgroup per trial, nPreamble > 64, more owned UEs than
 //     LDS holds, diagnostic options).
