@@ -1093,7 +1093,9 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
             } else {
                 if (ahead_for != t) {
                     compact_phase_a<false>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, activeCheck, mbev, tag, [] {});
+                    FSTAMP(15); // phase A (not run ahead)
                     __syncthreads(); // the queue is complete
+                    FSTAMP(16); // its barrier
                 }
                 compact_phase_b<0>(P, Lc, C, FM, fcallB, lcallB, t, prevAC, mbev, tag, 0ull);
             }

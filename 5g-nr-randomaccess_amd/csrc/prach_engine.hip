@@ -431,8 +431,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
                          dr.stamps6[4] / (double)dr.steps, dr.stamps6[5] / (double)dr.steps, dr.stamps6[6] / (double)dr.steps, dr.stamps6[7] / (double)dr.steps,
                          dr.dbg[0] / (double)dr.steps, dr.dbg[1], dr.dbg[2] / (double)dr.steps, (dr.dbg[3] >> 20) / (double)dr.steps, dr.dbg[3] & 0xfffff);
         if (std::getenv("PRACH_PRINT_STAMPS")) {
-            static const char *const nm[24] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "window-rest", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "-",
-                                               "w:phaseA", "w:loads", "w:refill", "t:buckets", "-", "-", "-", "-"};
+            static const char *const nm[24] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "window-rest", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "phaseA",
+                                               "w:phaseA|A-barrier", "w:loads", "w:refill", "t:buckets", "-", "-", "-", "-"};
             std::fprintf(stderr, "[prach fine stamps/step]");
             for (int q = 0; q < 20; q++) if (nm[q][0] != '-') std::fprintf(stderr, " %s=%.0f", nm[q], dr.fstamps[q] / (double)dr.steps);
             std::fprintf(stderr, "\n");

@@ -123,6 +123,30 @@ def traffic_from_profile():
         return None
 
 
+def relaunch_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` (N > 1) without a torch.distributed rendezvous in the environment: run the same command line as
+    N ranks in a child process.  Returns the child's exit code; a node with fewer than N GPUs is an error, not a smaller run."""
+    import socket
+    import torch  # (torch.cuda.device_count() does not initialise the GPU on this image; nothing else is called)
+    if not args.same_device and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} visible GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(p.stdout)
+    sys.stdout.flush()
+    if p.returncode == 0 and not any(l.startswith("{") and '"n_gpus": %d' % args.gpus in l for l in p.stdout.splitlines()):
+        print(f"bench.py: the {args.gpus}-rank child printed no JSON line with n_gpus = {args.gpus}", file=sys.stderr)
+        return 3
+    return p.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +162,13 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: nothing here has touched the GPU yet, so start the N ranks as a fresh
+        # child (one process per GPU under torch.distributed.run), relay its one JSON line and leave with its exit code.  It never
+        # degrades to a one-GPU run.
+        sys.exit(relaunch_under_torchrun(args))
     import torch
     import __graft_entry__ as g
     pkg = g.load_package()
@@ -145,8 +176,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if not args.same_device and torch.cuda.device_count() < args.gpus:  # (counting devices does not initialise the GPU)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} visible GPU(s)")
     dist = None
     if args.same_device:
         local_rank = 0
@@ -160,6 +194,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     eng = pkg.Engine(local_rank)
     grid = args.workload == "grid" or (args.workload == "auto" and world > 1)
@@ -261,10 +296,11 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
                      "dense_formulation_GBps_32B_per_update": ALGO_BYTES_PER_UPDATE * updates_per_step / world / (sum(kmss) / args.steps * 1e-3) / 1e9,
                      "note": "counter-measured HBM traffic of this regime (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes): profiles/r02_summary.md "
                              "(config 3: 3.58 TB/s = 45 % of peak, 1.9x the own bytes: the event body's scattered 4- and 8-byte accesses move whole sectors)"},
-        # the N = 1 line of the driver's scaling run is the single-trial workload (configs[1]); the one-GPU figure of THIS workload, for the
-        # strong-scaling efficiency of the grid, is the same command with `--gpus 1 --workload grid` (measured at the end of round 2)
-        "scaling_reference": {"n_gpus": 1, "workload": "this grid (--workload grid --times 1000)", "value": 7.91e11, "unit": "UE-subframe updates/s",
-                              "source": "DESIGN.md section 5 (one MI355X, end of round 2); rerun: python bench.py --gpus 1 --workload grid"},
+        # The N = 1 line of the driver's scaling run is the single-trial workload (configs[1]), a DIFFERENT workload: the one-GPU figure of this
+        # grid regime travels in that same N = 1 line as extras.grid_one_gpu (measured in that run, --times 100), and every N > 1 line carries
+        # value_per_gpu, so that a scaling efficiency can be formed from measured records only (no constant is pasted in here).
+        "value_per_gpu": value / world,
+        "one_gpu_reference": "extras.grid_one_gpu.kernel_updates_per_s / .wall_updates_per_s of the N = 1 record of the same run (or: python bench.py --gpus 1 --workload grid)",
         "success_ratio": {str(p): float(tot[k, fi["nSuccessUE"]]) / (args.times * p) for k, p in enumerate(points)},
         "results_csv_sha256": __import__("hashlib").sha256(csv_bytes).hexdigest(),
     }
@@ -377,6 +413,17 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
                     "reads 8 B per visited UE and does not rewrite a UE in steady contention, so this is NOT an HBM fraction: the counter traffic of "
                     "this launch (FETCH_SIZE / WRITE_SIZE, separate passes) is in profiles/",
             "mean_success_ratio_100k": sum(r_.nSuccessUE for c, r_ in zip(cfgs, rs) if c.nUE == 100000) / 100 / 1e5}
+        # (3b) the sharded grid's regime on ONE GPU (the denominator of the N > 1 lines' scaling): the Beta.c program's sweep x --times 100,
+        #      1000 trials in one call
+        cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_BETA_C, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(100) for n in range(10000, 100001, 10000)]
+        t1 = time.perf_counter()
+        rs, _ = eng.run_trials(cfgs)
+        wall = time.perf_counter() - t1
+        upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
+        tmg = eng.timing()
+        extras["grid_one_gpu"] = {"workload": "configs[4]'s grid with --times 100: 1000 Beta.c trials (nUE 10k..100k), one call, one launch",
+                                  "kernel_updates_per_s": upd / (tmg.kernel_ms * 1e-3), "wall_updates_per_s": upd / wall, "kernel_ms": tmg.kernel_ms,
+                                  "updates": upd, "trials": len(cfgs), "bad": sum(r_.status != 0 for r_ in rs), "fallback_trials": tmg.fallback_trials}
         # (4) BASELINE config 4: NOMA.c power-level grouping, nUE=100 000, one trial (activation tables built on all host cores: inclusive rate too)
         cfg = pkg.make_cfg(args.nue, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=0)
         (r,), _ = eng.run_trials([cfg])

@@ -551,11 +551,23 @@ def _run_bench_ranks(nranks, backend, extra, port):
     return json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
 
 
+def _run_bench_plain(nranks, backend, extra):
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run: bench.py must start its N ranks itself (never a silent one-GPU run)."""
+    import json
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "1", "--warmup", "0", "--times", "3", "--backend", backend] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.split("\n") if l.startswith("{")][-1])
+
+
 def _check_grid_line(pkg, ob, out, nranks):
     """bench.py's N>1 line is BASELINE configs[4] (the --times x sweep grid, strong scaling): the aggregates equal the
     oracle's, trial by trial, and so does results.csv."""
     import hashlib
     assert out["n_gpus"] == nranks and out["scaling"] == "strong" and out["config"]["trials_per_step"] == 30
+    assert out["value_per_gpu"] == out["value"] / nranks and "scaling_reference" not in out  # (no pasted one-GPU constant)
     assert len(out["per_rank_sim_seconds"]) == nranks and out["imbalance"] >= 0
     texts = {n: [] for n in range(10000, 100001, 10000)}
     succ = {n: 0 for n in texts}
@@ -581,6 +593,14 @@ def test_bench_grid_two_ranks_rehearsal(pkg, ob):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run), rehearsed on ONE GPU: both ranks on cuda:0, gloo
     for the collective (a one-GPU box has no second device for RCCL)."""
     _check_grid_line(pkg, ob, _run_bench_ranks(2, "gloo", ["--same-device"], 29541), 2)
+
+
+def test_bench_grid_two_ranks_plain_launch(pkg, ob):
+    """The same started as a plain `python bench.py --gpus 2 --same-device --backend gloo` (no torch.distributed.run, no rendezvous
+    variables): bench.py launches its two ranks itself and the line says n_gpus = 2 with the gloo backend."""
+    out = _run_bench_plain(2, "gloo", ["--same-device"])
+    assert out["config"]["collective_backend"] == "gloo"
+    _check_grid_line(pkg, ob, out, 2)
 
 
 def test_bench_grid_two_ranks_rccl(pkg, ob):

@@ -175,3 +175,16 @@ def test_results_csv_matches_numpy_csv_writer(pkg, tmp_path):
     # the shape of the reference's own file (results.csv:1): trailing zeros dropped, ".0" kept
     ref_like = pkg.results_csv([["10000\n100.00\n10000\n2.59\n47.11\n2.242"] * 4])
     assert ref_like == b"10000.0,100.0,10000.0,2.59,47.11,2.242\r\n"
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs exits non-zero with a message before anything runs
+    (it must never degrade to a one-GPU line); a WORLD_SIZE that contradicts --gpus is refused as well."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "visible GPU" in p.stderr and not any(l.startswith("{") for l in p.stdout.splitlines())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600,
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
