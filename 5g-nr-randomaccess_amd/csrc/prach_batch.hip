@@ -1,0 +1,650 @@
+// prach_batch.hip — the BATCHED regime: one workgroup per trial, thousands of trials in flight (BASELINE configs[2] / [4]: the
+// --times x nUE sweep).  The state of the in-flight trials streams through HBM every subframe, so what a UE costs per subframe is
+// what the pass READS of it and how many instructions the pass spends on it.
+//
+// Measured on prach::cluster_kernel's 8 + 4 byte form (round 3, diagnostic stamps, one 100 000-UE trial per workgroup): 79 % of a
+// subframe is the walk over the hot records, and that walk is bound by SCALAR instruction issue — ~55 scalar + ~45 vector
+// instructions per 64-UE visit, one scalar instruction per 4 cycles per SIMD: 92 k of 117 k cycles.  Hence this kernel:
+//
+//   * The walk reads ONE 32-bit PASS WORD per UE and nothing else:
+//         [15:0] tj   subframe from which the UE is matched by preambleCollision scans (its txTime)         0xFFFF: never
+//         [21:16] dur number of subframes it then contends with its RAR window open (Beta.c:245): matched in [tj, tj + dur)
+//         [29:24] preamble       [30] finished for good       [31] UL grant (set by the resolver with one atomicOr)
+//     A UE in steady contention is bumped every subframe (Beta.c:346,358) and counts one RAR-window subframe each time, so its
+//     whole trajectory until the window closes is known when it is scheduled: the walk only adds it to its bucket's histogram
+//     and keeps the bucket's lowest index (two LDS atomics), branch-free, and never writes.  A UE whose time has come
+//     (t == tj + dur: window expiry, Msg3, a deferred outcome) or that got a grant is an EVENT: its index goes to a queue.
+//   * Everything else about a UE — the 16-byte hot record of prach_device.h plus draw index, preambleTxCounter, failCount,
+//     first / second TxTime — is ONE 32-byte record, read and written only by the event body: an event is one 32-byte sector
+//     in, one out, plus the pass word (the general kernel touched up to seven arrays per event; profiles/r03_config3.md).
+//   * The event body is prach_ue_body.h (shared with every other kernel); the resolver is prach_cluster.hip's for one workgroup.
+//   * No per-subframe queue capacity: the event queue continues in global memory behind its LDS part.
+// Limits (the engine falls back to prach::cluster_kernel): Philox draws, nPreamble <= 64, maxRarWindow <= 64, < 65 000 subframes.
+// Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351; decomposition: DESIGN.md section 3.
+#include "prach_device.h"
+#include "prach_device_fn.h"
+#include "prach_ue_body.h"
+#include <limits.h>
+
+namespace prach {
+
+namespace {
+
+#ifdef PRACH_STAMPS
+#define BSTAMP(k)                                                                                      \
+    do {                                                                                               \
+        if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); fstamps[k] += now_ - fprev; fprev = now_; } \
+    } while (0)
+#else
+#define BSTAMP(k) do { } while (0)
+#endif
+
+constexpr int NPB = 64;       // stride of the per-bucket tables (nPreamble <= 64)
+constexpr int BEV = 4096;     // gathered events per subframe
+constexpr int BSC = 2048;     // singleton callers per subframe
+constexpr int BGB = 1024;     // grant selection bins
+#ifdef PRACH_QCAP
+constexpr int BQ = PRACH_QCAP; // (test build: nearly every subframe's queue continues in global memory)
+#else
+constexpr int BQ = 6144;      // event queue entries held in LDS (more: global memory)
+#endif
+constexpr int BPF = 4;        // pass words in flight per wavefront (groups fetched ahead)
+constexpr int BSTG = 64 + 64 * BPF + 64; // per-wavefront stage: event UEs collected before queue slots are taken for them (a round of BPF visits fits behind a leftover)
+constexpr int BLCAP = 512;    // live 64-UE groups per wavefront (8192 groups = 524 288 UEs per trial)
+
+constexpr unsigned PW_IDLE = 0x0000FFFFu;  // not arrived yet
+constexpr unsigned PW_DONE = 0x4000FFFFu;  // finished for good
+constexpr unsigned PW_GRANT = 0x80000000u;
+__device__ __forceinline__ unsigned pw_make(const int tj, const int dur, const int pre) {
+    return ((unsigned)tj & 0xFFFFu) | ((unsigned)dur << 16) | ((unsigned)pre << 24);
+}
+
+constexpr int EVB_CALLER = UEV_CALLER, EVB_RESETCAND = UEV_RESETCAND, EVB_RJOIN = UEV_RJOIN, EVB_LEAVER = 4;
+
+enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_SPARE, B_NEV, B_NCAND, B_QN, B_NCROSS, B_PTC, B_FC, B_SUMT = 16, B_ND = 18,
+       B_VISITS = 20, B_EVENTS = 21 };
+
+// ---- LDS layout: byte offsets, all compile-time ------------------------------------------------------------------------------------
+namespace bl {
+constexpr int GEV = 0;                          // int2 [BEV] events of this subframe
+constexpr int SIDX = GEV + 8 * BEV;             // int [BSC]
+constexpr int RCL = SIDX + 4 * BSC;             // int [RCCAP]
+constexpr int SCAL = RCL + 4 * RCCAP;           // int [64]
+constexpr int BINS = SCAL + 4 * 64;             // int [BGB]
+constexpr int WTOT = BINS + 4 * BGB;            // int [NW]
+// histogram and lowest index per bucket, each followed by 64 per-lane dummy words: a lane that is not matched adds to / takes the
+// minimum of its own dummy word, so the walk issues both atomics unconditionally (no exec-mask branch)
+constexpr int HISTX = WTOT + 4 * NW;            // int [NPB + 64]
+constexpr int MLOCX = HISTX + 4 * (NPB + 64);   // int [NPB + 64]
+constexpr int TOTAL = MLOCX + 4 * (NPB + 64);   // int [NPB]
+constexpr int FCALL = TOTAL + 4 * NPB;          // int [2][NPB] by subframe parity
+constexpr int LCALL = FCALL + 8 * NPB;          // int [2][NPB]
+constexpr int NLV = LCALL + 8 * NPB;            // int [NPB]
+constexpr int FIE = NLV + 4 * NPB;              // int [NPB]
+constexpr int LIST = FIE + 4 * NPB;             // unsigned short [NW][BLCAP + 16]: per wavefront, the 64-UE groups it still has to look at
+constexpr int QUEUE = LIST + 2 * NW * (BLCAP + 16); // int [BQ]
+constexpr int STAGE = QUEUE + 4 * BQ;           // int [NW][BSTG + 64]: stage, then 64 per-lane dummy words (a lane without an event writes there)
+constexpr int END = STAGE + 4 * NW * (BSTG + 64);
+static_assert(SIDX % 16 == 0 && LIST % 8 == 0 && (2 * (BLCAP + 16)) % 8 == 0, "alignment");
+} // namespace bl
+
+#define BI(off) (reinterpret_cast<int *>(smem + (off)))
+#define BU(off) (reinterpret_cast<unsigned *>(smem + (off)))
+#define BI2(off) (reinterpret_cast<int2 *>(smem + (off)))
+
+// the 32-byte event record: A = the hot record of prach_device.h {txTime, timer base, nowBackoff, packed}; B = {Philox draw index,
+// preambleTxCounter | failCount << 16, secondTxTime | firstTxTime << 16, the pass word it was scheduled with}
+struct BRec { int4 a, b; };
+__device__ __forceinline__ BRec brec_load(const PRACH_G v4i_t *p) {
+    const v4i_t a = p[0], b = p[1];
+    BRec r;
+    r.a = make_int4(a.x, a.y, a.z, a.w); r.b = make_int4(b.x, b.y, b.z, b.w);
+    return r;
+}
+__device__ __forceinline__ void brec_store(PRACH_G v4i_t *p, const int4 a, const int4 b) {
+    v4i_t va, vb;
+    va.x = a.x; va.y = a.y; va.z = a.z; va.w = a.w; vb.x = b.x; vb.y = b.y; vb.z = b.z; vb.w = b.w;
+    p[0] = va; p[1] = vb;
+}
+__device__ __forceinline__ ColdRegs cold_unpack(const int4 b) {
+    ColdRegs c;
+    c.ptc = b.y & 0xffff; c.fcnt = (int)((unsigned)b.y >> 16); c.stt = b.z & 0xffff; c.ftt = (int)((unsigned)b.z >> 16);
+    return c;
+}
+__device__ __forceinline__ int4 cold_pack(const unsigned nd, const ColdRegs &c, const unsigned word) {
+    return make_int4((int)nd, (c.ptc & 0xffff) | (c.fcnt << 16), (c.stt & 0xffff) | (c.ftt << 16), (int)word);
+}
+
+// A UE's record as the event body left it at some subframe s <= t - 1, brought to the start of subframe t: the deferred outcome of
+// subframe s (prach_ue_body.h ue_apply; a caller or matched UE was recorded with txTime = s + 1 already), then the subframes it was
+// matched in since according to the pass word it was scheduled with (sw, kept in the record) — bumped every time, one RAR-window
+// subframe each (Beta.c:245 + the txTime++ of Beta.c:346,358).
+template <class TAB>
+__device__ __forceinline__ void batch_catch_up(UeState &u, const unsigned sw, const bool granted, const int i, const int t, const FastMod fmA, const TAB &tab) {
+    const int tp = t - 1;
+    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) {
+        if (granted) { u.act = ACT_M3; u.tx = tp + 11; u.conn = 0; } // (a grant is applied the very next subframe: s == tp)
+        u.pend = PEND_NONE;
+    } else if (u.pend != PEND_NONE) {
+        ue_apply(u, granted, i, tp, fmA, tab); // (PEND_RESET / PASSIVE / RJOIN are always looked at the very next subframe)
+    } else if (granted) { // a matched UE that was its bucket's only member and called (Beta.c:332-343)
+        u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
+    }
+    const int stj = (int)(sw & 0xFFFFu), sdur = (int)((sw >> 16) & 0x3Fu);
+    if (sdur > 0 && t > stj) { u.rar += t - stj; if (!granted) u.tx = t; } // (a granted UE counted its window subframes too: Beta.c:245 runs before the call)
+}
+
+// the pass word of a UE after the event body of subframe t
+__device__ __forceinline__ unsigned batch_schedule(UeState &u, const int t, const int maxRar) {
+    if (u.act == ACT_DONE) return PW_DONE;
+    if (u.act == ACT_M3) return u.tx > t ? pw_make(u.tx, 0, 0) : PW_IDLE; // Msg3 / Msg4 at txTime (a txTime in the past never comes: Beta.c:167)
+    if (u.pend == PEND_RESET || u.pend == PEND_PASSIVE || u.pend == PEND_RJOIN) return pw_make(t + 1, 0, 0); // outcome needs the caller tables of t
+    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) u.tx = t + 1; // bumped, collided, or singleton without a grant (a grant: bit 31)
+    // The clean cases: asleep until txTime (nowBackoff runs out exactly then: every reschedule sets nowBackoff = txTime - time,
+    // Beta.c:279,305,399) or contending from the next subframe on (nowBackoff <= 0); from txTime on the UE is matched and counts its
+    // RAR window (Beta.c:245) until the window closes.  Anything else (never seen with the reference's parameters) is simply looked
+    // at again in the next subframe by the full body.
+    const bool clean = u.tx > t && (u.bo > 0 ? u.bo == u.tx : u.tx == t + 1);
+    if (!clean) return pw_make(t + 1, 0, u.pre - 1);
+    return pw_make(u.tx, max(0, maxRar - 1 - u.rar), u.pre - 1);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__restrict__ params) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TrialDev *const PD = params + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nUE = PD->nUE, nP = PD->nP, aT = PD->aT, stop = PD->stop, nGrantUL = PD->nGrantUL, binshift = PD->binshift;
+    const int variant = PD->variant;
+    const unsigned seed_lo = PD->seed_lo, seed_hi = PD->seed_hi;
+    UeK K;
+    K.maxRar = PD->maxRarWindow; K.maxMsg2 = PD->maxMsg2; K.aT = aT; K.withnoma = variant == PRACH_VARIANT_WITHNOMA_C;
+    K.fmP = make_fastmod(nP); K.fmB = make_fastmod(PD->backoff); K.fmA = make_fastmod(aT); K.fm5 = make_fastmod(5);
+    const bool withnoma = K.withnoma;
+    PRACH_G v4i_t *const rec32 = (PRACH_G v4i_t *)PD->rec32;     // [nUE][2]
+    PRACH_G unsigned *const pw = (PRACH_G unsigned *)PD->pw;     // [whole groups] pass words
+    PRACH_G int *const qov = (PRACH_G int *)PD->qov;             // [nUE] event queue beyond its LDS part
+    PRACH_G v2i_t *const cand = (PRACH_G v2i_t *)PD->cand;       // early-leaver candidates of a subframe
+    const PRACH_G int *const sched = (const PRACH_G int *)PD->sched;
+    int *const scal = BI(bl::SCAL);
+    int2 *const gev = BI2(bl::GEV);
+    int *const queue = BI(bl::QUEUE);
+    unsigned short *const lst = reinterpret_cast<unsigned short *>(smem + bl::LIST) + w * (BLCAP + 16); // this wavefront's live groups
+    int *const histx = BI(bl::HISTX), *const mlocx = BI(bl::MLOCX);
+    int *const stage = BI(bl::STAGE) + w * (BSTG + 64);
+
+    const int totgroups = (nUE + 63) >> 6;
+    // calloc + initialUE (Beta.c:78-83)
+    for (int i = tid; i < (totgroups + 1) * 64; i += WG_THREADS) {
+        if (i < nUE) brec_store(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0), make_int4(0, 0, 0, (int)PW_IDLE));
+        pw[i] = i < nUE ? PW_IDLE : PW_DONE; // (padded to whole 64-UE groups, plus the padding group the list's empty entries point at)
+    }
+    if (tid < NPB) {
+        BI(bl::HISTX)[tid] = 0; BI(bl::MLOCX)[tid] = INT_MAX; BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0;
+        BI(bl::FCALL)[tid] = INT_MAX; BI(bl::FCALL)[NPB + tid] = INT_MAX; BI(bl::LCALL)[tid] = -1; BI(bl::LCALL)[NPB + tid] = -1;
+    }
+    if (tid < 64) scal[tid] = 0;
+    if (lane < 16) lst[lane] = (unsigned short)totgroups; // empty list: padding entries only
+    __syncthreads();
+
+    int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
+    int nlive = 0; // entries of this wavefront's list (wave-uniform)
+    unsigned long long steps = 0;
+    int status = (nP > NPB || K.maxRar > 64 || stop > 65000 || totgroups > NW * BLCAP || nUE >= (1 << 20)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+#ifdef PRACH_STAMPS
+    unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
+#endif
+
+    for (int t = 0; t < stop && status == PRACH_OK; t++) {
+        steps++;
+        tlast = t;
+        if (t % 5 == 0) grantCheck = 0; // Beta.c:112 (hard-coded 5)
+        const int prevAC = activeCheck;
+        if (t % aT == 0 && activeCheck != nUE) activeCheck = sched[t / aT]; // Beta.c:121-134
+        const int parity = t & 1;
+        int *const fcallA = BI(bl::FCALL) + parity * NPB, *const lcallA = BI(bl::LCALL) + parity * NPB;
+        int *const fcallB = BI(bl::FCALL) + (parity ^ 1) * NPB, *const lcallB = BI(bl::LCALL) + (parity ^ 1) * NPB;
+        BSTAMP(0); // loop head
+
+        // ================= the walk: one pass word per UE =================
+        {
+            int sc = 0; // staged event UEs of this wavefront (wave-uniform)
+            auto flush = [&]() __attribute__((always_inline)) { // the stage goes to the event queue in one piece: one returning LDS atomic per ~100 event UEs
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&scal[B_QN], sc);
+                base = __builtin_amdgcn_readfirstlane(base);
+                for (int o = 0; o < sc; o += 64) {
+                    if (o + lane < sc) {
+                        const int e = stage[o + lane], q = base + o + lane;
+                        if (q < BQ) queue[q] = e; else qov[q - BQ] = e;
+                    }
+                }
+                sc = 0;
+            };
+            if (w == NW - 1 && activeCheck > prevAC) { // this access slot's arrivals (Beta.c:136-146) are events
+                for (int i0 = prevAC; i0 < activeCheck; i0 += 64) {
+                    if (i0 + lane < activeCheck) stage[sc + lane] = i0 + lane;
+                    sc += min(64, activeCheck - i0);
+                    if (sc > BSTG - 64 * BPF) flush();
+                }
+            }
+            // groups the arrival front has reached since the last subframe join this wavefront's list (group g belongs to wavefront g % NW)
+            {
+                const int g0 = (prevAC + 63) >> 6, g1 = (activeCheck + 63) >> 6;
+                if (g1 > g0) {
+                    int g = g0 + ((w - g0) & (NW - 1));
+                    const int before = nlive;
+                    for (; g < g1 && nlive < BLCAP; g += NW) { if (lane == 0) lst[nlive] = (unsigned short)g; nlive++; } // (totgroups <= NW * BLCAP: checked above)
+                    if (nlive != before && lane < 12) lst[nlive + lane] = (unsigned short)totgroups; // behind the last entry: the padding group (finished words)
+                }
+            }
+            const bool retire = (t & 7) == (w & 7); // finished groups are looked for every 8th subframe (wave-uniform)
+            int nnull = 0;                            // list entries found finished in this subframe
+            // One 64-UE group: matched UEs go to their bucket's histogram / lowest index (Beta.c:321-330 sees them), UEs whose time has come
+            // onto the stage; every other lane hits its own dummy word — no exec-mask branch.  g: the group (same value in every lane).
+            auto visit = [&](const unsigned g, const unsigned uw, const int k) __attribute__((always_inline)) {
+                const int i = (int)(g * 64u) + lane;
+                const int dd = t - (int)(uw & 0xFFFFu);
+                const int dur = (int)((uw >> 16) & 0x3Fu);
+                const unsigned long long mGrant = __ballot((int)uw < 0);
+                const unsigned long long mMember = __ballot((unsigned)dd < (unsigned)dur) & ~mGrant;
+                const unsigned long long mHeavy = __ballot(dd >= dur) | mGrant; // (never / not yet arrived / padding: tj = 0xFFFF)
+                const bool member = __builtin_amdgcn_inverse_ballot_w64(mMember), heavy = __builtin_amdgcn_inverse_ballot_w64(mHeavy);
+                const int bx = member ? (int)((uw >> 24) & 0x3Fu) : NPB + lane;
+                atomicAdd(&histx[bx], 1);
+                atomicMin(&mlocx[bx], i);
+                const int cnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mHeavy >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mHeavy, 0u));
+                stage[heavy ? sc + cnt : BSTG + lane] = i | (int)(uw & PW_GRANT);
+                sc += __builtin_amdgcn_readfirstlane(__popcll(mHeavy));
+                if (retire && (mMember | mHeavy) == 0ull && __ballot((uw & 0x40000000u) != 0u) == ~0ull && g != (unsigned)totgroups) {
+                    if (lane == 0) lst[k] = (unsigned short)totgroups; // every UE of the group has finished: the entry becomes padding
+                    nnull++;
+                }
+            };
+            // Software pipeline over the list, BPF groups per round: the entries of round r + 2 are read from LDS (one ds_read_b64, the same
+            // address in every lane), the pass words of round r + 1 are in flight, round r is worked on.  The list ends with >= 8 padding entries.
+            auto ld_ent = [&](const int k) -> uint2 { return *reinterpret_cast<const uint2 *>(lst + k); };
+            auto ent = [&](const uint2 E, const int d) -> unsigned { return d == 0 ? (E.x & 0xFFFFu) : d == 1 ? (E.x >> 16) : d == 2 ? (E.y & 0xFFFFu) : (E.y >> 16); };
+            // (unconditional loads of mapped memory — the array is padded by one group of "finished" words; non-temporal = past this CU's L1,
+            //  because the grant bit is set by an L2 atomic)
+            auto ld_pw = [&](const unsigned g) -> unsigned { return __builtin_nontemporal_load(pw + (g * 64u + (unsigned)lane)); };
+            const int npad = (nlive + BPF - 1) & ~(BPF - 1);
+            uint2 E0 = ld_ent(0), E1 = ld_ent(BPF);
+            unsigned W0[BPF];
+#pragma unroll
+            for (int d = 0; d < BPF; d++) W0[d] = ld_pw(ent(E0, d));
+            for (int k = 0; k < npad; k += BPF) {
+                const uint2 E2 = ld_ent(k + 2 * BPF);
+                unsigned W1[BPF];
+#pragma unroll
+                for (int d = 0; d < BPF; d++) W1[d] = ld_pw(ent(E1, d));
+#pragma unroll
+                for (int d = 0; d < BPF; d++) visit(ent(E0, d), W0[d], k + d);
+#pragma unroll
+                for (int d = 0; d < BPF; d++) W0[d] = W1[d];
+                E0 = E1; E1 = E2;
+                if (sc > BSTG - 64 * BPF) flush(); // (the ONE place the walk empties its stage)
+            }
+            if (sc > 0) flush();
+            if (nnull > 0) { // (rare: a group dies once per trial) squeeze the finished entries out of the list
+                int out = 0;
+                for (int base = 0; base < nlive; base += 64) {
+                    const bool in = base + lane < nlive;
+                    const unsigned short e = in ? lst[base + lane] : (unsigned short)totgroups;
+                    const unsigned long long km = __ballot(in && e != (unsigned short)totgroups);
+                    if ((km >> lane) & 1ull) lst[out + __popcll(km & lanemask_lt(lane))] = e;
+                    out += __popcll(km);
+                }
+                nlive = out;
+                if (lane < 12) lst[nlive + lane] = (unsigned short)totgroups;
+            }
+            if (lane == 0 && npad) atomicAdd(&scal[B_VISITS], npad); // (reported, never read by the simulation)
+        }
+        BSTAMP(1); // walk
+        __syncthreads(); // the queue is complete
+        BSTAMP(2);
+
+        // ================= the event body: queued UEs, 64 at a time =================
+        {
+            int c_succ = 0, c_contf = 0;
+            const int qn = scal[B_QN];
+            const int tmod = t % aT;
+            const CallTables tab{fcallB, lcallB};
+            for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
+                const int q = q0 + lane;
+                const bool v = q < qn;
+                int e = 0;
+                if (v) e = q < BQ ? queue[q] : qov[q - BQ];
+                const int i = e & 0x7FFFFFFF;
+                const bool granted = e < 0;
+                BRec R;
+                R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0);
+                if (v) R = brec_load(rec32 + 2 * (size_t)i);
+                UeState u = unpack(R.a);
+                ColdRegs cold = cold_unpack(R.b);
+                unsigned nd = (unsigned)R.b.x;
+                if (v) batch_catch_up(u, (unsigned)R.b.w, granted, i, t, K.fmA, tab);
+                if (v && i >= prevAC && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
+                    ue_activate(u, i, t, cold);
+                    if (withnoma) nd = 2;
+                }
+                const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
+                int d1 = 0, d2 = 0;
+                if (__any(pl.need > 0)) {
+                    d1 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd, (unsigned)nUE, (unsigned)variant);
+                    if (__any(pl.need > 1)) d2 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd + 1u, (unsigned)nUE, (unsigned)variant);
+                    nd += (unsigned)pl.need;
+                }
+                const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
+                // ---- bucket bookkeeping ----
+                if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
+                if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i);
+                if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i);
+                {
+                    const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(o.eclass);
+                    if (em | cm) {
+                        int b_ev = 0, b_cd = 0;
+                        if (lane == 0) {
+                            if (em) b_ev = atomicAdd(&scal[B_NEV], __popcll(em));
+                            if (cm) b_cd = atomicAdd(&scal[B_NCAND], __popcll(cm));
+                        }
+                        b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
+                        if (o.evtype != UEV_NONE) {
+                            const int es = b_ev + __popcll(em & lanemask_lt(lane));
+                            if (es < BEV) gev[es] = make_int2(i, ue_event_info(o));
+                        }
+                        if (o.eclass) store_i2(&cand[b_cd + __popcll(cm & lanemask_lt(lane))], i, o.oldp);
+                    }
+                }
+                if (v) {
+                    const unsigned word = batch_schedule(u, t, K.maxRar);
+                    brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, cold, word));
+                    pw[i] = word;
+                }
+            }
+            if (__any((c_succ | c_contf) != 0)) {
+                c_succ = wave_sum(c_succ); c_contf = wave_sum(c_contf);
+                if (lane == 0) {
+                    if (c_succ) atomicAdd(&scal[B_NSUCC], c_succ);
+                    if (c_contf) atomicAdd(&scal[B_CONTF], c_contf);
+                }
+            }
+        }
+        BSTAMP(3); // event body
+        __syncthreads(); // S1: histogram / lowest callers / candidate list are complete; the caller tables of t - 1 are free
+        BSTAMP(4);
+
+        // early leavers below the bucket's lowest caller are the only ones a rank can need
+        {
+            const int ncand = scal[B_NCAND];
+            for (int k = tid; k < ncand; k += WG_THREADS) {
+                const v2i_t c = cand[k];
+                if (c.x < mlocx[c.y]) {
+                    const int es = atomicAdd(&scal[B_NEV], 1);
+                    if (es < BEV) gev[es] = make_int2(c.x, EVB_LEAVER | (c.y << 4));
+                }
+            }
+            if (tid < NPB) { lcallB[tid] = -1; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; }
+            if (tid == 0) {
+                scal[B_EVENTS] += scal[B_QN]; // (reported, never read by the simulation)
+                scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0; scal[B_QN] = 0;
+            }
+        }
+        BSTAMP(5); // leaver filter
+        __syncthreads(); // S2
+        BSTAMP(6);
+        const int N = scal[B_NEV];
+        if (tid < NPB) { // this workgroup's histogram / lowest callers ARE the totals
+            BI(bl::TOTAL)[tid] = BI(bl::HISTX)[tid]; fcallA[tid] = BI(bl::MLOCX)[tid];
+            BI(bl::HISTX)[tid] = 0; BI(bl::MLOCX)[tid] = INT_MAX;
+        }
+        if (N > BEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on trial_kernel
+        __syncthreads(); // S3
+        if (tid == 0) { scal[B_NEV] = 0; scal[B_NCAND] = 0; }
+        const int nsucc_tot = scal[B_NSUCC];
+        // classify the events against the lowest DEFINITE caller of every bucket
+        for (int k = tid; k < N; k += WG_THREADS) {
+            const int2 ev = gev[k];
+            const int type = ev.y & 7, p = (ev.y >> 4) & 0xff;
+            if (type == EVB_RESETCAND) {
+                // a call on its old bucket by a definite caller with a lower index bumps it: cannot re-join (99.7 % of them)
+                if (fcallA[(ev.y >> 12) & 0xff] < ev.x) gev[k].y = 0;
+                else { const int s = atomicAdd(&scal[B_NRC], 1); if (s < RCCAP) BI(bl::RCL)[s] = k; }
+            } else if (type == EVB_RJOIN) {
+                atomicAdd(&scal[B_NRJ], 1);
+            } else if (type == EVB_LEAVER) {
+                if (ev.x < fcallA[p]) atomicAdd(&BI(bl::NLV)[p], 1);
+            } else if (type == EVB_CALLER) {
+                if (ev.x == fcallA[p]) BI(bl::FIE)[p] = 1;
+            }
+        }
+        BSTAMP(7); // classify
+        if (N > 0) __syncthreads(); // S4 (N is uniform)
+        BSTAMP(8);
+
+        // ---- resolve ----
+        const int nrc = scal[B_NRC];
+        if (nrc > 0) { // rare: reset cycles that may re-join — decided strictly in index order by one wavefront, then recount
+            if (nrc > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (tid < 64) { // (first-caller table in registers, lane = bucket: prach_cluster.hip resolve_reset_candidates)
+                const int n = __builtin_amdgcn_readfirstlane(nrc);
+                int *const rcl = BI(bl::RCL), *const sidx = BI(bl::SIDX);
+                int f0 = lane < nP ? fcallA[lane] : INT_MAX;
+                for (int c = lane; c < n; c += 64) { // rank-sort the candidates by UE index into SIDX (free at this point)
+                    const int myidx = gev[rcl[c]].x;
+                    int rank = 0;
+                    for (int j = 0; j < n; j++) rank += gev[rcl[j]].x < myidx ? 1 : 0;
+                    sidx[rank] = rcl[c];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int base = 0; base < n; base += 64) {
+                    const int mm = min(64, n - base);
+                    int es = 0, cidx = 0, cinfo = 0;
+                    if (lane < mm) { es = sidx[base + lane]; const int2 e = gev[es]; cidx = e.x; cinfo = e.y; }
+                    int cancelled = 0;
+                    for (int s_ = 0; s_ < mm; s_++) {
+                        const int idx = __builtin_amdgcn_readlane(cidx, s_), info = __builtin_amdgcn_readlane(cinfo, s_);
+                        const int p = (info >> 4) & 0xff, q = (info >> 12) & 0xff;
+                        if (__builtin_amdgcn_readlane(f0, q & 63) < idx) { if (lane == s_) cancelled = 1; } // bumped before its turn
+                        else if (idx < __builtin_amdgcn_readlane(f0, p & 63)) { if (lane == (p & 63)) f0 = idx; } // its call becomes the first on p
+                    }
+                    if (lane < mm && cancelled) gev[es].y = 0;
+                }
+                if (lane < nP) fcallA[lane] = f0;
+            } else if (tid < 64 + NPB) { BI(bl::NLV)[tid - 64] = 0; BI(bl::FIE)[tid - 64] = 0; }
+            __syncthreads();
+            for (int k = tid; k < N; k += WG_THREADS) {
+                const int2 e = gev[k];
+                const int type = e.y & 7, p = (e.y >> 4) & 0xff;
+                if (type == EVB_LEAVER) { if (e.x < fcallA[p]) atomicAdd(&BI(bl::NLV)[p], 1); }
+                else if ((type == EVB_CALLER || type == EVB_RESETCAND) && e.x == fcallA[p]) BI(bl::FIE)[p] = 1;
+            }
+            __syncthreads();
+        }
+        // every call: scan count `check` (Beta.c:321-330), counters (Beta.c:334,349-351 / WithNOMA:650-652)
+        {
+            const int nrj = scal[B_NRJ];
+            int my_coll = 0, my_txop = 0;
+            for (int k = tid; k < N + nP; k += WG_THREADS) {
+                int idx = 0, p = 0, ispre = 0;
+                bool caller = false;
+                if (k < N) {
+                    const int2 e = gev[k];
+                    const int type = e.y & 7;
+                    if (type == EVB_CALLER || type == EVB_RESETCAND) { caller = true; idx = e.x; p = (e.y >> 4) & 0xff; ispre = (e.y >> 3) & 1; }
+                } else {
+                    p = k - N;
+                    if (fcallA[p] != INT_MAX && !BI(bl::FIE)[p]) { caller = true; idx = fcallA[p]; ispre = 1; } // a matched UE calls first
+                }
+                if (!caller) continue;
+                const bool first = idx == fcallA[p];
+                int rj = 0;
+                if (nrj > 0) { // Msg3-timeout re-entries that stayed matched since the previous call on this bucket (rare)
+                    int prev = (!first) ? fcallA[p] : -1;
+                    for (int j = 0; j < N; j++) {
+                        const int2 ej = gev[j];
+                        const int tj = ej.y & 7;
+                        if ((tj == EVB_CALLER || tj == EVB_RESETCAND) && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) prev = ej.x;
+                    }
+                    for (int j = 0; j < N; j++) {
+                        const int2 ej = gev[j];
+                        if ((ej.y & 7) == EVB_RJOIN && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) rj++;
+                    }
+                }
+                const int check = 1 + (first ? BI(bl::TOTAL)[p] - ispre - BI(bl::NLV)[p] : 0) + rj;
+                if (lcallA[p] < idx) atomicMax(&lcallA[p], idx);
+                if (check == 1) {
+                    const int s = atomicAdd(&scal[B_NS], 1);
+                    if (s < BSC) BI(bl::SIDX)[s] = idx;
+                    my_txop += 1;
+                } else if (withnoma) { // WithNOMA:650-652
+                    my_coll += check; my_txop += check;
+                } else { // Beta.c:349-351
+                    my_coll += 1; my_txop += 1;
+                }
+            }
+            if (__any((my_coll | my_txop) != 0)) {
+                my_coll = wave_sum(my_coll); my_txop = wave_sum(my_txop);
+                if (lane == 0) { if (my_coll) atomicAdd(&scal[B_COLL], my_coll); if (my_txop) atomicAdd(&scal[B_TXOP], my_txop); }
+            }
+        }
+        BSTAMP(9); // calls
+        __syncthreads(); // S5: calls done; singles listed
+        BSTAMP(10);
+        const int ns = scal[B_NS];
+        if (ns > BSC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+        const int Gr = max(0, nGrantUL - 1 - grantCheck); // Beta.c:336-347
+        auto grant = [&](const int my) { __hip_atomic_fetch_or(pw + my, PW_GRANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // ONE fire-and-forget L2 atomic
+        if (Gr > 0 && ns > 0 && ns <= 64) {
+            if (tid < 64) { // up to one wavefront of singleton callers: every lane ranks its own index against the others through v_readlane
+                const int nsu = __builtin_amdgcn_readfirstlane(ns);
+                const int my = tid < nsu ? BI(bl::SIDX)[tid] : INT_MAX;
+                int rank = 0;
+                for (int s_ = 0; s_ < nsu; s_++) rank += __builtin_amdgcn_readlane(my, s_) < my ? 1 : 0;
+                if (tid < nsu && rank < Gr) grant(my);
+            }
+        } else if (Gr > 0 && ns > 0) {
+            // the Gr lowest-index singleton callers, in O(ns): counts per index bin, block-wide exclusive prefix, whole bins below the
+            // crossing bin are granted, the crossing bin is ranked exactly
+            int *const bins = BI(bl::BINS), *const sidx = BI(bl::SIDX), *const rcl = BI(bl::RCL), *const wtot = BI(bl::WTOT);
+            bins[tid] = 0;
+            if (tid == 0) scal[B_NCROSS] = 0;
+            __syncthreads();
+            for (int j = tid; j < ns; j += WG_THREADS) atomicAdd(&bins[sidx[j] >> binshift], 1);
+            __syncthreads();
+            {
+                const int c = bins[tid];
+                const int x = wave_scan_incl(c);
+                if (lane == 63) wtot[w] = x;
+                __syncthreads();
+                int add = 0;
+                for (int k = 0; k < w; k++) add += wtot[k];
+                bins[tid] = x - c + add; // exclusive prefix
+            }
+            __syncthreads();
+            for (int j = tid; j < ns; j += WG_THREADS) {
+                const int my = sidx[j];
+                const int bin = my >> binshift;
+                const int before = bins[bin];
+                if (before >= Gr) continue;
+                const int cnt = (bin + 1 < BGB ? bins[bin + 1] : ns) - before;
+                if (before + cnt <= Gr) grant(my);
+                else { const int s_ = atomicAdd(&scal[B_NCROSS], 1); if (s_ < RCCAP) rcl[s_] = my; }
+            }
+            __syncthreads();
+            const int ncross = scal[B_NCROSS];
+            if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (tid < ncross) {
+                const int my = rcl[tid];
+                int rank = bins[my >> binshift];
+                for (int m = 0; m < ncross; m++) rank += rcl[m] < my ? 1 : 0;
+                if (rank < Gr) grant(my);
+            }
+        }
+        grantCheck += ns;
+        BSTAMP(11); // grants
+        if (Gr > 0 && ns > 0) __syncthreads(); // S6: the grants are in the pass words before the next walk reads them
+        BSTAMP(12);
+        if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
+    }
+    __syncthreads();
+
+    // ---- the state after the last subframe (deferred outcome + the subframes a UE was matched in since its record was written),
+    // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508)
+    const int tend = tlast + 1;
+    {
+        const CallTables tab{BI(bl::FCALL) + (tlast & 1) * NPB, BI(bl::LCALL) + (tlast & 1) * NPB};
+        PRACH_G int *const timers = (PRACH_G int *)PD->timers;
+        PRACH_G v4i_t *const logs = (PRACH_G v4i_t *)PD->logs;
+        long long sumT = 0;
+        int ptcS = 0, fcS = 0;
+        unsigned long long ndS = 0;
+        for (int i = tid; i < nUE; i += WG_THREADS) {
+            const BRec R = brec_load(rec32 + 2 * (size_t)i);
+            UeState u = unpack(R.a);
+            const ColdRegs cold = cold_unpack(R.b);
+            if (status == PRACH_OK && tlast >= 0 && u.act != ACT_IDLE)
+                batch_catch_up(u, (unsigned)R.b.w, (int)__builtin_nontemporal_load(pw + i) < 0, i, tend, K.fmA, tab);
+            const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
+            if (u.act == ACT_DONE) { sumT += timer; ptcS += cold.ptc; fcS += cold.fcnt; }
+            ndS += (unsigned)R.b.x;
+            timers[i] = u.act == ACT_DONE ? timer : INT_MIN;
+            if (logs) {
+                prach_ue_log o;
+                o.idx = i; o.timer = timer; o.active = u.act - 1; o.txTime = u.tx; o.firstTxTime = cold.ftt;
+                o.secondTxTime = cold.stt; o.nowBackoff = now_backoff(u.bo, tend); o.preamble = u.pre - 1;
+                o.preambleChange = u.pre != 0; o.rarWindow = u.rar; o.maxRarCounter = u.mrc; o.preambleTxCounter = cold.ptc;
+                o.msg2Flag = (u.act == ACT_M3 || u.act == ACT_DONE); o.connectionRequest = u.conn == 2 ? 48 : u.conn;
+                o.msg4Flag = u.act == ACT_DONE; o.failCount = cold.fcnt;
+                store_log(logs, i, o);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            sumT += __shfl_down(sumT, d); ptcS += __shfl_down(ptcS, d); fcS += __shfl_down(fcS, d); ndS += __shfl_down(ndS, d);
+        }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&scal[B_SUMT]), (unsigned long long)sumT);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&scal[B_ND]), ndS);
+            atomicAdd(&scal[B_PTC], ptcS);
+            atomicAdd(&scal[B_FC], fcS);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { // DevResult was zeroed by the engine before the launch
+        PRACH_G DevResult *o = (PRACH_G DevResult *)PD->out;
+        o->sumTimer = *reinterpret_cast<long long *>(&scal[B_SUMT]);
+        o->draws = *reinterpret_cast<unsigned long long *>(&scal[B_ND]);
+        o->ptcSum = scal[B_PTC]; o->fcSum = scal[B_FC];
+        o->nSuccess = scal[B_NSUCC]; o->finalSuccess = scal[B_NSUCC]; o->continueFailed = scal[B_CONTF];
+        o->status = status;
+        o->time_exit = time_exit;
+        o->collisionPreambles = scal[B_COLL]; o->totalPreambleTxop = scal[B_TXOP];
+        o->activeCheck = activeCheck;
+        o->steps = steps;
+        o->visits = (unsigned long long)(unsigned)scal[B_VISITS];
+        o->events = (unsigned long long)(unsigned)scal[B_EVENTS];
+#ifdef PRACH_STAMPS
+        for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];
+#endif
+    }
+}
+
+size_t batch_kernel_lds_bytes() { return (size_t)bl::END; }
+int batch_max_preambles() { return NPB; }
+int batch_max_rar_window() { return 64; }
+int batch_max_subframes() { return 65000; }
+
+hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, hipStream_t stream) {
+    const size_t lds = batch_kernel_lds_bytes();
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL(batch_kernel, dim3(ntrials), dim3(WG_THREADS), lds, stream, params);
+    return hipGetLastError();
+}
+
+} // namespace prach

@@ -53,6 +53,7 @@ struct prach_engine {
     bool pack_off = false;         // (set for the rerun of a packed launch that timed out)
     int64_t opt_two_per_cu = 0;    // 1: the streaming regime on the small LDS layout, two 1024-thread workgroups per CU (measured slower: DESIGN.md section 4)
     int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
+    int64_t opt_batch = 1;         // 0: one-workgroup-per-trial Philox launches run on the general kernel instead of prach_batch.hip
     int num_cus = 256;
 };
 
@@ -63,6 +64,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, cand;
     size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0, sector;
+    size_t rec32, pw, qov; // batch kernel
     size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
     int evw, mbstride;
@@ -91,7 +93,7 @@ size_t mbox_bytes(const prach_cfg &c, int G, int &evw, int &mbstride) {
 }
 
 // stream_len[k]: glibc draw-stream window of trial k (0 in Philox mode); G: workgroups per trial (0 = trial_kernel)
-LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_ue_log *const *ue_logs, const std::vector<size_t> &stream_len, int G) {
+LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_ue_log *const *ue_logs, const std::vector<size_t> &stream_len, int G, bool batch) {
     LaunchLayout L;
     L.t.resize(m);
     size_t o = align_up(sizeof(TrialDev) * (size_t)m, 256);
@@ -118,8 +120,13 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         const prach_cfg &c = cfgs[idx[k]];
         TrialLayout &T = L.t[k];
         const size_t n = (size_t)c.nUE;
-        T.rec = take(16 * n);
-        T.ptc = take(4 * n); T.ftt = take(4 * n); T.stt = take(4 * n); T.fcnt = take(4 * n); T.nd = take(4 * n);
+        T.rec = T.ptc = T.ftt = T.stt = T.fcnt = T.nd = T.rec32 = T.pw = T.qov = 0;
+        if (batch) { // prach_batch.hip: 32-byte event records, pass words padded to whole 64-UE groups, the queue's global part
+            T.rec32 = take(32 * n); T.pw = take(4 * ((n + 63) / 64 * 64 + 64)); T.qov = take(4 * n);
+        } else {
+            T.rec = take(16 * n);
+            T.ptc = take(4 * n); T.ftt = take(4 * n); T.stt = take(4 * n); T.fcnt = take(4 * n); T.nd = take(4 * n);
+        }
         T.evbuf = T.evbuf2 = T.sidx = T.cand = 0;
         if (G == 0) { // trial_kernel only: event / singleton scratch without a per-subframe capacity
             T.evbuf = take(sizeof(Event) * n); T.evbuf2 = take(sizeof(Event) * n);
@@ -240,7 +247,13 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (rng_mode == PRACH_RNG_GLIBC) slen[k] = (size_t)stream_budget(c, attempt, e->opt_stream_factor);
         if (c.nPreamble > maxP) maxP = c.nPreamble;
     }
-    const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G);
+    // one workgroup per trial, Philox: the batch kernel (prach_batch.hip), within its limits
+    bool batch = G == 1 && !noma && rng_mode == PRACH_RNG_PHILOX && e->opt_batch && !e->opt_dense && !e->opt_wide_records && maxP <= batch_max_preambles();
+    for (int k = 0; k < m && batch; k++) {
+        const prach_cfg &c = cfgs[idx[k]];
+        batch = c.maxRarWindow <= batch_max_rar_window() && (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1;
+    }
+    const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G, batch);
     { int rc = ensure_arena(e, LL.end); if (rc != PRACH_OK) return rc; }
     { int rc = ensure_pinned(e, std::max(LL.staged_end, sizeof(DevResult) * (size_t)m)); if (rc != PRACH_OK) return rc; }
     auto t0 = std::chrono::steady_clock::now();
@@ -261,10 +274,14 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.stream_len = L.stream_len;
         d.dense_pass = e->opt_dense ? 1 : 0;
         d.pipeline = e->opt_pipeline ? 1 : 0;
-        d.rec = reinterpret_cast<int4 *>(A + L.rec);
-        d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);
-        d.stt = reinterpret_cast<int *>(A + L.stt); d.fcnt = reinterpret_cast<int *>(A + L.fcnt);
-        d.nd = reinterpret_cast<unsigned *>(A + L.nd);
+        if (batch) {
+            d.rec32 = reinterpret_cast<int4 *>(A + L.rec32); d.pw = reinterpret_cast<unsigned *>(A + L.pw); d.qov = reinterpret_cast<int *>(A + L.qov);
+        } else {
+            d.rec = reinterpret_cast<int4 *>(A + L.rec);
+            d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);
+            d.stt = reinterpret_cast<int *>(A + L.stt); d.fcnt = reinterpret_cast<int *>(A + L.fcnt);
+            d.nd = reinterpret_cast<unsigned *>(A + L.nd);
+        }
         d.evbuf = L.evbuf ? reinterpret_cast<Event *>(A + L.evbuf) : nullptr;
         d.evbuf2 = L.evbuf2 ? reinterpret_cast<Event *>(A + L.evbuf2) : nullptr;
         d.sidx = L.sidx ? reinterpret_cast<int *>(A + L.sidx) : nullptr;
@@ -361,6 +378,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         const int xpack = e->opt_xcd_pack && !e->pack_off && G > 1 && ((m + 7) / 8) * G <= e->num_cus / 8;
         e->last.xcd_packed = xpack;
         HIPCHK(launch_noma_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, xpack, e->stream));
+    }
+    else if (batch) {
+        e->last.rec_mode = CLUSTER_REC_BATCH;
+        e->last.xcd_packed = 0;
+        HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, e->stream));
     }
     else if (G > 0) {
         // one workgroup per trial = the streaming regime: 8 + 4 byte hot records, if every subframe number of every trial of
@@ -659,6 +681,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "host_threads") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_host_threads = value; return PRACH_OK; }
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "batch") == 0) { e->opt_batch = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "xcd_pack") == 0) { e->opt_xcd_pack = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "two_per_cu") == 0) { e->opt_two_per_cu = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;

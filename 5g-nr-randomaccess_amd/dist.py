@@ -70,35 +70,44 @@ def allreduce_aggregates(agg: np.ndarray, device=None):
     return t.cpu().numpy()
 
 
-ROW_BYTES = 120  # a row = (trial index, short text): index in 8 bytes + up to 112 bytes of text
+ROW_BYTES = 256  # a row = trial index (8 bytes) + kind (1) + payload length (2) + up to ROW_PAYLOAD bytes of text
+ROW_PAYLOAD = ROW_BYTES - 11  # (Beta.c's six-line Results.txt is ~45 bytes, RandomAccessWithNOMA's eight lines ~115 at nUE = 100 000)
+
+
+def _row_payload(val):
+    if isinstance(val, (int, np.integer)):
+        return str(int(val)).encode(), b"i"
+    return (val if isinstance(val, bytes) else str(val).encode()), b"s"
 
 
 def gather_trial_rows(rows, dst: int = 0, device=None):
     """Per-trial rows [(trial index, text or int), ...] gathered to `dst` in rank order; None elsewhere.
     Carried by ONE tensor all-gather of fixed-size byte records (a native collective of RCCL and gloo alike — no pickled-object
-    collective on the critical path of the multi-GPU bench); every rank pads to the largest shard."""
+    collective on the critical path of the multi-GPU bench); every rank pads to the largest shard.  A row that does not fit its record
+    fails on EVERY rank together: the sizes travel with the shard lengths in the first all-gather, before any payload moves."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        for _, val in rows:
+            if len(_row_payload(val)[0]) > ROW_PAYLOAD:
+                raise ValueError(f"row text of {len(_row_payload(val)[0])} bytes does not fit the {ROW_BYTES}-byte record")
         return list(rows)
     world = dist.get_world_size()
-    n = torch.tensor([len(rows)], dtype=torch.int64)
+    packed = [(int(idx),) + _row_payload(val) for idx, val in rows]
+    longest = max((len(p) for _, p, _ in packed), default=0)
+    n = torch.tensor([len(rows), longest], dtype=torch.int64)
     if device is not None:
         n = n.to(device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    nmax = max(int(c.item()) for c in counts)
-    buf = np.zeros((max(nmax, 1), ROW_BYTES), dtype=np.uint8)
-    kinds = set()
-    for k, (idx, val) in enumerate(rows):
-        if isinstance(val, (int, np.integer)):
-            payload, kind = str(int(val)).encode(), b"i"
-        else:
-            payload, kind = (val if isinstance(val, bytes) else str(val).encode()), b"s"
-        if len(payload) > ROW_BYTES - 10:
-            raise ValueError(f"row text of {len(payload)} bytes does not fit the {ROW_BYTES}-byte record")
-        kinds.add(kind)
-        rec = int(idx).to_bytes(8, "little") + kind + bytes([len(payload)]) + payload
+    heads = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(heads, n)
+    heads = [h.cpu() for h in heads]
+    worst = max(int(h[1]) for h in heads)
+    if worst > ROW_PAYLOAD:  # every rank sees the same numbers: all of them stop here, none is left waiting in the next collective
+        raise ValueError(f"row text of {worst} bytes (on some rank) does not fit the {ROW_BYTES}-byte record")
+    counts = [int(h[0]) for h in heads]
+    buf = np.zeros((max(max(counts), 1), ROW_BYTES), dtype=np.uint8)
+    for k, (idx, payload, kind) in enumerate(packed):
+        rec = idx.to_bytes(8, "little") + kind + len(payload).to_bytes(2, "little") + payload
         buf[k, :len(rec)] = np.frombuffer(rec, dtype=np.uint8)
     t = torch.from_numpy(buf)
     if device is not None:
@@ -110,10 +119,10 @@ def gather_trial_rows(rows, dst: int = 0, device=None):
     out = []
     for r in range(world):
         a = parts[r].cpu().numpy()
-        for k in range(int(counts[r].item())):
+        for k in range(counts[r]):
             raw = a[k].tobytes()
             idx = int.from_bytes(raw[:8], "little")
-            ln = raw[9]
-            payload = raw[10:10 + ln]
+            ln = int.from_bytes(raw[9:11], "little")
+            payload = raw[11:11 + ln]
             out.append((idx, int(payload) if raw[8:9] == b"i" else payload.decode()))
     return out

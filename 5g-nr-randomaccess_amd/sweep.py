@@ -69,9 +69,12 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     agg = distmod.aggregate_rows([cfgs[i] for i in mine], res, points)
     tot = distmod.allreduce_aggregates(agg, device=dev if (world > 1 and args.backend == "nccl") else None)
-    # per-trial Results.txt texts (Beta.c's six lines; latency 0) travel to rank 0 for the exact results.csv
-    rows = [(i, pkg.format_results(cfgs[i], r, 0.0).decode()) for i, r in zip(mine, res)]
-    allrows = distmod.gather_trial_rows(rows, dst=0, device=dev if (world > 1 and args.backend == "nccl") else None)
+    # per-trial Results.txt texts (Beta.c's six lines; latency 0) travel to rank 0 for the exact results.csv — only where they are
+    # consumed: AveragePerformance.py reads the Beta.c program's files
+    allrows = None
+    if variant == pkg.VARIANT_BETA_C:
+        rows = [(i, pkg.format_results(cfgs[i], r, 0.0).decode()) for i, r in zip(mine, res)]
+        allrows = distmod.gather_trial_rows(rows, dst=0, device=dev if (world > 1 and args.backend == "nccl") else None)
     if rank == 0:
         fi = {n: k for k, n in enumerate(distmod.AGG_FIELDS)}
         summary = {"program": args.program, "times": args.times, "points": points, "world": world,

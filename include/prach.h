@@ -112,12 +112,16 @@ typedef struct prach_timing {
     int32_t fallback_trials; /* trials of the last call that a cluster launch could not finish and that were rerun (exactly) on
                                 a kernel that waits for nobody: a per-subframe capacity exceeded, or a peer wait timed out */
     int32_t spin_timeouts;   /* ... of which: peer waits that timed out (PRACH_ERR_TIMEOUT) */
-    int32_t rec_mode;        /* last cluster launch: 0 records in global memory (16 B), 1 global 8 + 4 B (one workgroup per trial),
-                                2 resident in LDS for the whole trial (clusters, Philox) */
+    int32_t rec_mode;        /* which kernel / record form the last cluster launch used: 0 prach::cluster_kernel, 16-byte records in global
+                                memory; 1 the same with 8 + 4 byte records (one workgroup per trial: the glibc modes); 2 the same with
+                                records resident in LDS (clusters, Philox); 3 prach::lcluster_kernel (the lean LDS-resident cluster
+                                kernel: single Philox trials, the bench's N = 1 workload); 4 prach::batch_kernel (one workgroup per
+                                trial, 4-byte pass words + 32-byte event records: the batched sweeps, Philox) */
     int32_t xcd_packed;   /* 1: the last cluster launch was XCD-packed (each cluster on the CUs of one XCD; prach_engine_set "xcd_pack") */
-    uint64_t group_visits;   /* cluster_kernel (records in global memory): 64-UE group visits of the pass's phase A, summed over the call */
-    uint64_t event_ues;      /* ... and UEs that went through its full event body: the kernel's OWN memory work, for a roofline built
-                                from the bytes it really moves (a visit reads one hot record per lane, an event reads and writes a UE) */
+    uint64_t group_visits;   /* one workgroup per trial: 64-UE group visits of the pass, summed over the call */
+    uint64_t event_ues;      /* ... and UEs that went through the full event body: the kernel's OWN memory work, for a roofline built from
+                                the bytes it really moves (batch_kernel: a visit reads one 4-byte pass word per lane, an event reads and
+                                writes one 32-byte record and one pass word) */
 } prach_timing;
 
 typedef struct prach_engine prach_engine;
@@ -142,7 +146,10 @@ int prach_last_timing(const prach_engine *, prach_timing *out);
  *   "pipeline"      0: a cluster does not run phase A of the next subframe during the exchange of the current one
  *   "resident"      test hook: treat only this many workgroups as co-resident (0 = ask the runtime's occupancy query)
  *   "host_threads"  NOMA_C: host threads that build the activation tables (0 = all cores)
- *   "lds_records"   0: clusters keep their UE records in global memory instead of LDS */
+ *   "lds_records"   0: clusters keep their UE records in global memory instead of LDS
+ *   "fast"          0: LDS-resident clusters run on the general cluster kernel instead of prach::lcluster_kernel
+ *   "batch"         0: one-workgroup-per-trial Philox launches run on the general cluster kernel instead of prach::batch_kernel
+ *   "xcd_pack"      0: clusters are not launched XCD-packed;  "two_per_cu" 1: small LDS layout of the general kernel (diagnostic) */
 int prach_engine_set(prach_engine *, const char *key, int64_t value);
 
 /* Host-side pieces of the same seam (no device needed) */
@@ -163,7 +170,8 @@ const char *prach_strerror(int status);
  * 10*log(high)-10*log(low)), and the number of draws the activation consumed.  The double-precision
  * libm work (cos, sin, log, pow) runs ONCE per UE here on the host, with the same libm the reference links,
  * so the device-side sort / pairing is bit-identical to the reference; the per-subframe loop is on the GPU.
- * Philox mode only (draw k of UE i; the rejection loops make the glibc stream position data dependent). */
+ * This table form is the Philox mode's (draw k of UE i is independent of every other UE).  In glibc mode the rejection loops make
+ * every stream position data dependent: there the engine activates arrivals one by one with prach_noma_activation_stream below. */
 int prach_noma_activation_table(const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
                                 uint32_t *ndraws);
 /* the same for the UEs [lo, hi) only (outputs indexed from lo): ranges are independent, the engine builds them on all host cores */

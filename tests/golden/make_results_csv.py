@@ -14,9 +14,9 @@ What it does
      tests/golden/results_csv.json.
 
 tests/test_host_logic.py then compares prach_results_csv_accumulate / prach_results_csv_row (host C,
-csrc/prach_host.c) with those bytes, and tests/test_gpu_parity.py the CLI's --csv on a sub-grid whose
-expected bytes come from the same script run (second fixture block, 3 seeds x 3 points is NOT possible with
-the unmodified script — it hard-codes 100 seeds x 10 points — so the CLI is checked on the full texts).
+csrc/prach_host.c) with those bytes, and tests/test_gpu_parity.py runs the same 1000-trial experiment through
+the CLI on the GPU and compares the first five columns of its --csv with them (the sixth is wall clock).  There
+is ONE fixture block: the unmodified script hard-codes 100 seeds x 10 points, so no smaller grid can be pinned.
 
 Usage:  python tests/golden/make_results_csv.py [--threads 8]
 """

@@ -80,6 +80,55 @@ def test_two_rank_gloo_sharded_sweep(ob, pkg):
     assert rows == exp_rows
 
 
+def _rows_worker(rank, world, port, q, mode):
+    """gather_trial_rows with text rows: RandomAccessWithNOMA's eight-line Results.txt (the longest row the drivers produce) and, in
+    mode "too_long", one row on rank 1 only that does not fit — every rank must raise, none may hang in the payload collective."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    from oracle import binding as ob
+    g.load_package()
+    import importlib
+    distmod = importlib.import_module("nr_randomaccess_amd.dist")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ocfg = ob.make_cfg(1500, variant=1)
+    r, _ = ob.run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, rank), want_ues=False)
+    r.nSuccessUE, r.totalPreambleTxop, r.continueFaliedUEs = 99999, 2147483647, 2147483647  # (the widest numbers the format can print)
+    text = ob.format_results(ocfg, r).decode() + "0.000000"
+    rows = [(10 * rank + k, text) for k in range(2 + rank)]
+    if mode == "too_long" and rank == 1:
+        rows.append((99, "x" * (distmod.ROW_PAYLOAD + 1)))
+    try:
+        out = distmod.gather_trial_rows(rows, dst=0)
+        q.put((rank, "ok", out, text))
+    except ValueError as e:
+        q.put((rank, "ValueError", str(e), text))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["withnoma_text", "too_long"])
+def test_two_rank_gloo_text_rows(ob, pkg, mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if mode == "too_long":
+        assert [o[1] for o in outs] == ["ValueError", "ValueError"]  # together, before the payload collective
+        return
+    assert [o[1] for o in outs] == ["ok", "ok"] and outs[1][2] is None
+    texts = {o[0]: o[3] for o in outs}
+    assert len(texts[0]) > 110  # (the old 120-byte record could not carry this row)
+    assert outs[0][2] == [(0, texts[0]), (1, texts[0]), (10, texts[1]), (11, texts[1]), (12, texts[1])]
+
+
 def test_shard_trials_properties(pkg):
     import importlib
     distmod = importlib.import_module("nr_randomaccess_amd.dist")
