@@ -25,6 +25,7 @@
 #include "prach_device_fn.h"
 #include "prach_ue_body.h"
 #include <limits.h>
+#include <type_traits>
 
 namespace prach {
 
@@ -40,17 +41,23 @@ namespace {
 #endif
 
 constexpr int NPB = 64;       // stride of the per-bucket tables (nPreamble <= 64)
-constexpr int BEV = 4096;     // gathered events per subframe
 constexpr int BSC = 2048;     // singleton callers per subframe
 constexpr int BGB = 1024;     // grant selection bins
-#ifdef PRACH_QCAP
-constexpr int BQ = PRACH_QCAP; // (test build: nearly every subframe's queue continues in global memory)
-#else
-constexpr int BQ = 6144;      // event queue entries held in LDS (more: global memory)
-#endif
 constexpr int BPF = 4;        // pass words in flight per wavefront (groups fetched ahead)
 constexpr int BSTG = 64 + 64 * BPF + 64; // per-wavefront stage: event UEs collected before queue slots are taken for them (a round of BPF visits fits behind a leftover)
-constexpr int BLCAP = 512;    // live 64-UE groups per wavefront (8192 groups = 524 288 UEs per trial)
+constexpr int BGROUPS = 8192; // 64-UE groups per trial at most (524 288 UEs): live-group lists of BGROUPS / NWB entries per wavefront
+// Workgroup shapes.  NWB wavefronts per workgroup: 16 (1024 threads, one workgroup = one trial per CU) or 8 (512 threads and an LDS
+// footprint under 80 KB, so that TWO workgroups = two independent trials share a CU: while one waits at a barrier or for its event
+// records, the other one issues).  Per-subframe capacities of the resolver's lists (more: the engine reruns the trial on trial_kernel):
+template <int NWB> struct BCap {
+    static constexpr int EV = NWB == 16 ? 4096 : 2048;  // gathered events
+#ifdef PRACH_QCAP
+    static constexpr int Q = PRACH_QCAP;                  // (test build: nearly every subframe's queue continues in global memory)
+#else
+    static constexpr int Q = NWB == 16 ? 6144 : 2048;   // event queue entries held in LDS (more: global memory)
+#endif
+    static constexpr int LCAP = BGROUPS / NWB;            // live 64-UE groups per wavefront
+};
 
 constexpr unsigned PW_IDLE = 0x0000FFFFu;  // not arrived yet
 constexpr unsigned PW_DONE = 0x4000FFFFu;  // finished for good
@@ -65,28 +72,30 @@ enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_SPARE, B_NEV,
        B_VISITS = 20, B_EVENTS = 21 };
 
 // ---- LDS layout: byte offsets, all compile-time ------------------------------------------------------------------------------------
-namespace bl {
-constexpr int GEV = 0;                          // int2 [BEV] events of this subframe
-constexpr int SIDX = GEV + 8 * BEV;             // int [BSC]
-constexpr int RCL = SIDX + 4 * BSC;             // int [RCCAP]
-constexpr int SCAL = RCL + 4 * RCCAP;           // int [64]
-constexpr int BINS = SCAL + 4 * 64;             // int [BGB]
-constexpr int WTOT = BINS + 4 * BGB;            // int [NW]
-// histogram and lowest index per bucket, each followed by 64 per-lane dummy words: a lane that is not matched adds to / takes the
-// minimum of its own dummy word, so the walk issues both atomics unconditionally (no exec-mask branch)
-constexpr int HISTX = WTOT + 4 * NW;            // int [NPB + 64]
-constexpr int MLOCX = HISTX + 4 * (NPB + 64);   // int [NPB + 64]
-constexpr int TOTAL = MLOCX + 4 * (NPB + 64);   // int [NPB]
-constexpr int FCALL = TOTAL + 4 * NPB;          // int [2][NPB] by subframe parity
-constexpr int LCALL = FCALL + 8 * NPB;          // int [2][NPB]
-constexpr int NLV = LCALL + 8 * NPB;            // int [NPB]
-constexpr int FIE = NLV + 4 * NPB;              // int [NPB]
-constexpr int LIST = FIE + 4 * NPB;             // unsigned short [NW][BLCAP + 16]: per wavefront, the 64-UE groups it still has to look at
-constexpr int QUEUE = LIST + 2 * NW * (BLCAP + 16); // int [BQ]
-constexpr int STAGE = QUEUE + 4 * BQ;           // int [NW][BSTG + 64]: stage, then 64 per-lane dummy words (a lane without an event writes there)
-constexpr int END = STAGE + 4 * NW * (BSTG + 64);
-static_assert(SIDX % 16 == 0 && LIST % 8 == 0 && (2 * (BLCAP + 16)) % 8 == 0, "alignment");
-} // namespace bl
+template <int NWB> struct BL {
+    using C = BCap<NWB>;
+    static constexpr int GEV = 0;                          // int2 [EV] events of this subframe
+    static constexpr int SIDX = GEV + 8 * C::EV;           // int [BSC]
+    static constexpr int RCL = SIDX + 4 * BSC;             // int [RCCAP]
+    static constexpr int SCAL = RCL + 4 * RCCAP;           // int [64]
+    static constexpr int BINS = SCAL + 4 * 64;             // int [BGB]
+    static constexpr int WTOT = BINS + 4 * BGB;            // int [16]
+    // histogram and lowest index per bucket, each followed by 64 per-lane dummy words: a lane that is not matched adds to / takes the
+    // minimum of its own dummy word, so the walk issues both atomics unconditionally (no exec-mask branch)
+    static constexpr int HISTX = WTOT + 4 * 16;            // int [NPB + 64]
+    static constexpr int MLOCX = HISTX + 4 * (NPB + 64);   // int [NPB + 64]
+    static constexpr int TOTAL = MLOCX + 4 * (NPB + 64);   // int [NPB]
+    static constexpr int FCALL = TOTAL + 4 * NPB;          // int [2][NPB] by subframe parity
+    static constexpr int LCALL = FCALL + 8 * NPB;          // int [2][NPB]
+    static constexpr int NLV = LCALL + 8 * NPB;            // int [NPB]
+    static constexpr int FIE = NLV + 4 * NPB;              // int [NPB]
+    static constexpr int LIST = FIE + 4 * NPB;             // unsigned short [NWB][LCAP + 16]: per wavefront, the 64-UE groups it still has to look at
+    static constexpr int QUEUE = LIST + 2 * NWB * (C::LCAP + 16); // int [Q]
+    static constexpr int STAGE = QUEUE + 4 * C::Q;         // int [NWB][BSTG + 64]: stage, then 64 per-lane dummy words (a lane without an event writes there)
+    static constexpr int END = STAGE + 4 * NWB * (BSTG + 64);
+    static_assert(SIDX % 16 == 0 && LIST % 8 == 0 && (2 * (C::LCAP + 16)) % 8 == 0, "alignment");
+};
+static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
 
 #define BI(off) (reinterpret_cast<int *>(smem + (off)))
 #define BU(off) (reinterpret_cast<unsigned *>(smem + (off)))
@@ -96,7 +105,7 @@ static_assert(SIDX % 16 == 0 && LIST % 8 == 0 && (2 * (BLCAP + 16)) % 8 == 0, "a
 // preambleTxCounter | failCount << 16, secondTxTime | firstTxTime << 16, the pass word it was scheduled with}
 struct BRec { int4 a, b; };
 __device__ __forceinline__ BRec brec_load(const PRACH_G v4i_t *p) {
-    const v4i_t a = p[0], b = p[1];
+    const v4i_t a = p[0], b = p[1]; // (plain loads and stores: non-temporal ones cost 30 % on config 3 — a record's line is read again soon)
     BRec r;
     r.a = make_int4(a.x, a.y, a.z, a.w); r.b = make_int4(b.x, b.y, b.z, b.w);
     return r;
@@ -152,8 +161,11 @@ __device__ __forceinline__ unsigned batch_schedule(UeState &u, const int t, cons
 } // namespace
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__restrict__ params) {
+template <int NWB>
+__global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restrict__ params) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using bl = BL<NWB>;
+    constexpr int TB = NWB * 64, BEV = BCap<NWB>::EV, BQ = BCap<NWB>::Q, BLCAP = BCap<NWB>::LCAP;
     const TrialDev *const PD = params + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nUE = PD->nUE, nP = PD->nP, aT = PD->aT, stop = PD->stop, nGrantUL = PD->nGrantUL, binshift = PD->binshift;
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
 
     const int totgroups = (nUE + 63) >> 6;
     // calloc + initialUE (Beta.c:78-83)
-    for (int i = tid; i < (totgroups + 1) * 64; i += WG_THREADS) {
+    for (int i = tid; i < (totgroups + 1) * 64; i += TB) {
         if (i < nUE) brec_store(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0), make_int4(0, 0, 0, (int)PW_IDLE));
         pw[i] = i < nUE ? PW_IDLE : PW_DONE; // (padded to whole 64-UE groups, plus the padding group the list's empty entries point at)
     }
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
     int nlive = 0; // entries of this wavefront's list (wave-uniform)
     unsigned long long steps = 0;
-    int status = (nP > NPB || K.maxRar > 64 || stop > 65000 || totgroups > NW * BLCAP || nUE >= (1 << 20)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (nP > NPB || K.maxRar > 64 || stop > 65000 || totgroups > BGROUPS || nUE >= (1 << 20)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
 #ifdef PRACH_STAMPS
     unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
 #endif
@@ -223,20 +235,20 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
                 }
                 sc = 0;
             };
-            if (w == NW - 1 && activeCheck > prevAC) { // this access slot's arrivals (Beta.c:136-146) are events
+            if (w == NWB - 1 && activeCheck > prevAC) { // this access slot's arrivals (Beta.c:136-146) are events
                 for (int i0 = prevAC; i0 < activeCheck; i0 += 64) {
                     if (i0 + lane < activeCheck) stage[sc + lane] = i0 + lane;
                     sc += min(64, activeCheck - i0);
                     if (sc > BSTG - 64 * BPF) flush();
                 }
             }
-            // groups the arrival front has reached since the last subframe join this wavefront's list (group g belongs to wavefront g % NW)
+            // groups the arrival front has reached since the last subframe join this wavefront's list (group g belongs to wavefront g % NWB)
             {
                 const int g0 = (prevAC + 63) >> 6, g1 = (activeCheck + 63) >> 6;
                 if (g1 > g0) {
-                    int g = g0 + ((w - g0) & (NW - 1));
+                    int g = g0 + ((w - g0) & (NWB - 1));
                     const int before = nlive;
-                    for (; g < g1 && nlive < BLCAP; g += NW) { if (lane == 0) lst[nlive] = (unsigned short)g; nlive++; } // (totgroups <= NW * BLCAP: checked above)
+                    for (; g < g1 && nlive < BLCAP; g += NWB) { if (lane == 0) lst[nlive] = (unsigned short)g; nlive++; } // (totgroups <= NWB * BLCAP: checked above)
                     if (nlive != before && lane < 12) lst[nlive + lane] = (unsigned short)totgroups; // behind the last entry: the padding group (finished words)
                 }
             }
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
             int nnull = 0;                            // list entries found finished in this subframe
             // One 64-UE group: matched UEs go to their bucket's histogram / lowest index (Beta.c:321-330 sees them), UEs whose time has come
             // onto the stage; every other lane hits its own dummy word — no exec-mask branch.  g: the group (same value in every lane).
-            auto visit = [&](const unsigned g, const unsigned uw, const int k) __attribute__((always_inline)) {
+            auto visit = [&](auto RETIRE, const unsigned g, const unsigned uw, const int k) __attribute__((always_inline)) {
                 const int i = (int)(g * 64u) + lane;
                 const int dd = t - (int)(uw & 0xFFFFu);
                 const int dur = (int)((uw >> 16) & 0x3Fu);
@@ -255,38 +267,46 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
                 const int bx = member ? (int)((uw >> 24) & 0x3Fu) : NPB + lane;
                 atomicAdd(&histx[bx], 1);
                 atomicMin(&mlocx[bx], i);
-                const int cnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mHeavy >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mHeavy, 0u));
-                stage[heavy ? sc + cnt : BSTG + lane] = i | (int)(uw & PW_GRANT);
+                int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mHeavy >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mHeavy, (unsigned)sc)); // sc + rank among the event lanes
+                asm volatile("" : "+v"(slot)); // (computed for every lane: two VALU instructions are cheaper than the exec-mask branch the compiler wraps them in)
+                stage[heavy ? slot : BSTG + lane] = i | (int)(uw & PW_GRANT);
                 sc += __builtin_amdgcn_readfirstlane(__popcll(mHeavy));
-                if (retire && (mMember | mHeavy) == 0ull && __ballot((uw & 0x40000000u) != 0u) == ~0ull && g != (unsigned)totgroups) {
-                    if (lane == 0) lst[k] = (unsigned short)totgroups; // every UE of the group has finished: the entry becomes padding
-                    nnull++;
+                if (decltype(RETIRE)::value) { // (only the walk of every 8th subframe is compiled with this)
+                    if ((mMember | mHeavy) == 0ull && __ballot((uw & 0x40000000u) != 0u) == ~0ull && g != (unsigned)totgroups) {
+                        if (lane == 0) lst[k] = (unsigned short)totgroups; // every UE of the group has finished: the entry becomes padding
+                        nnull++;
+                    }
                 }
             };
             // Software pipeline over the list, BPF groups per round: the entries of round r + 2 are read from LDS (one ds_read_b64, the same
             // address in every lane), the pass words of round r + 1 are in flight, round r is worked on.  The list ends with >= 8 padding entries.
             auto ld_ent = [&](const int k) -> uint2 { return *reinterpret_cast<const uint2 *>(lst + k); };
             auto ent = [&](const uint2 E, const int d) -> unsigned { return d == 0 ? (E.x & 0xFFFFu) : d == 1 ? (E.x >> 16) : d == 2 ? (E.y & 0xFFFFu) : (E.y >> 16); };
-            // (unconditional loads of mapped memory — the array is padded by one group of "finished" words; non-temporal = past this CU's L1,
-            //  because the grant bit is set by an L2 atomic)
-            auto ld_pw = [&](const unsigned g) -> unsigned { return __builtin_nontemporal_load(pw + (g * 64u + (unsigned)lane)); };
+            // (unconditional loads of mapped memory — the array is padded by one group of "finished" words.  A relaxed agent-scope load =
+            //  global_load_dword ... sc1: served by L2, never by this CU's L1, because the grant bit is set by an L2 atomic.  NOT a
+            //  non-temporal load: the words are read again every subframe, and marked streaming they lose their place in L2 / the
+            //  Infinity Cache to the event records — measured 905 -> 827 ms on config 3, 398 -> 374 / 366 -> 310 ms on 1000 Beta.c trials)
+            auto ld_pw = [&](const unsigned g) -> unsigned { return __hip_atomic_load(pw + (g * 64u + (unsigned)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
             const int npad = (nlive + BPF - 1) & ~(BPF - 1);
-            uint2 E0 = ld_ent(0), E1 = ld_ent(BPF);
-            unsigned W0[BPF];
+            auto walk = [&](auto RETIRE) __attribute__((always_inline)) {
+                uint2 E0 = ld_ent(0), E1 = ld_ent(BPF);
+                unsigned W0[BPF];
 #pragma unroll
-            for (int d = 0; d < BPF; d++) W0[d] = ld_pw(ent(E0, d));
-            for (int k = 0; k < npad; k += BPF) {
-                const uint2 E2 = ld_ent(k + 2 * BPF);
-                unsigned W1[BPF];
+                for (int d = 0; d < BPF; d++) W0[d] = ld_pw(ent(E0, d));
+                for (int k = 0; k < npad; k += BPF) {
+                    const uint2 E2 = ld_ent(k + 2 * BPF);
+                    unsigned W1[BPF];
 #pragma unroll
-                for (int d = 0; d < BPF; d++) W1[d] = ld_pw(ent(E1, d));
+                    for (int d = 0; d < BPF; d++) W1[d] = ld_pw(ent(E1, d));
 #pragma unroll
-                for (int d = 0; d < BPF; d++) visit(ent(E0, d), W0[d], k + d);
+                    for (int d = 0; d < BPF; d++) visit(RETIRE, ent(E0, d), W0[d], k + d);
 #pragma unroll
-                for (int d = 0; d < BPF; d++) W0[d] = W1[d];
-                E0 = E1; E1 = E2;
-                if (sc > BSTG - 64 * BPF) flush(); // (the ONE place the walk empties its stage)
-            }
+                    for (int d = 0; d < BPF; d++) W0[d] = W1[d];
+                    E0 = E1; E1 = E2;
+                    if (sc > BSTG - 64 * BPF) flush(); // (the ONE place the walk empties its stage)
+                }
+            };
+            if (retire) walk(std::true_type{}); else walk(std::false_type{});
             if (sc > 0) flush();
             if (nnull > 0) { // (rare: a group dies once per trial) squeeze the finished entries out of the list
                 int out = 0;
@@ -312,16 +332,26 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
             const int qn = scal[B_QN];
             const int tmod = t % aT;
             const CallTables tab{fcallB, lcallB};
-            for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
+            struct Batch { int e; bool v; BRec R; };
+            auto fetch_batch = [&](const int q0) -> Batch { // (record 0 is always mapped: an idle lane loads it and ignores it)
+                Batch B;
                 const int q = q0 + lane;
-                const bool v = q < qn;
-                int e = 0;
-                if (v) e = q < BQ ? queue[q] : qov[q - BQ];
+                B.v = q < qn;
+                B.e = 0;
+                if (B.v) B.e = q < BQ ? queue[q] : qov[q - BQ];
+                B.R = brec_load(rec32 + 2 * (size_t)(B.e & 0x7FFFFFFF));
+                return B;
+            };
+            Batch Bn = fetch_batch(w * 64);
+            for (int q0 = w * 64; q0 < qn; q0 += NWB * 64) {
+                const Batch Bc = Bn;
+                if (q0 + NWB * 64 < qn) Bn = fetch_batch(q0 + NWB * 64); // in flight while this batch is worked on
+                const bool v = Bc.v;
+                const int e = Bc.e;
                 const int i = e & 0x7FFFFFFF;
                 const bool granted = e < 0;
-                BRec R;
-                R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0);
-                if (v) R = brec_load(rec32 + 2 * (size_t)i);
+                BRec R = Bc.R;
+                if (!v) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
                 UeState u = unpack(R.a);
                 ColdRegs cold = cold_unpack(R.b);
                 unsigned nd = (unsigned)R.b.x;
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
         // early leavers below the bucket's lowest caller are the only ones a rank can need
         {
             const int ncand = scal[B_NCAND];
-            for (int k = tid; k < ncand; k += WG_THREADS) {
+            for (int k = tid; k < ncand; k += TB) {
                 const v2i_t c = cand[k];
                 if (c.x < mlocx[c.y]) {
                     const int es = atomicAdd(&scal[B_NEV], 1);
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
         if (tid == 0) { scal[B_NEV] = 0; scal[B_NCAND] = 0; }
         const int nsucc_tot = scal[B_NSUCC];
         // classify the events against the lowest DEFINITE caller of every bucket
-        for (int k = tid; k < N; k += WG_THREADS) {
+        for (int k = tid; k < N; k += TB) {
             const int2 ev = gev[k];
             const int type = ev.y & 7, p = (ev.y >> 4) & 0xff;
             if (type == EVB_RESETCAND) {
@@ -457,7 +487,7 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
                 if (lane < nP) fcallA[lane] = f0;
             } else if (tid < 64 + NPB) { BI(bl::NLV)[tid - 64] = 0; BI(bl::FIE)[tid - 64] = 0; }
             __syncthreads();
-            for (int k = tid; k < N; k += WG_THREADS) {
+            for (int k = tid; k < N; k += TB) {
                 const int2 e = gev[k];
                 const int type = e.y & 7, p = (e.y >> 4) & 0xff;
                 if (type == EVB_LEAVER) { if (e.x < fcallA[p]) atomicAdd(&BI(bl::NLV)[p], 1); }
@@ -469,7 +499,7 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
         {
             const int nrj = scal[B_NRJ];
             int my_coll = 0, my_txop = 0;
-            for (int k = tid; k < N + nP; k += WG_THREADS) {
+            for (int k = tid; k < N + nP; k += TB) {
                 int idx = 0, p = 0, ispre = 0;
                 bool caller = false;
                 if (k < N) {
@@ -531,22 +561,27 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
             // the Gr lowest-index singleton callers, in O(ns): counts per index bin, block-wide exclusive prefix, whole bins below the
             // crossing bin are granted, the crossing bin is ranked exactly
             int *const bins = BI(bl::BINS), *const sidx = BI(bl::SIDX), *const rcl = BI(bl::RCL), *const wtot = BI(bl::WTOT);
-            bins[tid] = 0;
+            constexpr int PER = BGB / TB; // consecutive bins per thread
+#pragma unroll
+            for (int u_ = 0; u_ < PER; u_++) bins[tid * PER + u_] = 0;
             if (tid == 0) scal[B_NCROSS] = 0;
             __syncthreads();
-            for (int j = tid; j < ns; j += WG_THREADS) atomicAdd(&bins[sidx[j] >> binshift], 1);
+            for (int j = tid; j < ns; j += TB) atomicAdd(&bins[sidx[j] >> binshift], 1);
             __syncthreads();
             {
-                const int c = bins[tid];
-                const int x = wave_scan_incl(c);
+                int c[PER], sum = 0;
+#pragma unroll
+                for (int u_ = 0; u_ < PER; u_++) { c[u_] = bins[tid * PER + u_]; sum += c[u_]; }
+                const int x = wave_scan_incl(sum);
                 if (lane == 63) wtot[w] = x;
                 __syncthreads();
-                int add = 0;
-                for (int k = 0; k < w; k++) add += wtot[k];
-                bins[tid] = x - c + add; // exclusive prefix
+                int run = x - sum;
+                for (int k = 0; k < w; k++) run += wtot[k];
+#pragma unroll
+                for (int u_ = 0; u_ < PER; u_++) { bins[tid * PER + u_] = run; run += c[u_]; } // exclusive prefix
             }
             __syncthreads();
-            for (int j = tid; j < ns; j += WG_THREADS) {
+            for (int j = tid; j < ns; j += TB) {
                 const int my = sidx[j];
                 const int bin = my >> binshift;
                 const int before = bins[bin];
@@ -583,12 +618,12 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
         long long sumT = 0;
         int ptcS = 0, fcS = 0;
         unsigned long long ndS = 0;
-        for (int i = tid; i < nUE; i += WG_THREADS) {
+        for (int i = tid; i < nUE; i += TB) {
             const BRec R = brec_load(rec32 + 2 * (size_t)i);
             UeState u = unpack(R.a);
             const ColdRegs cold = cold_unpack(R.b);
             if (status == PRACH_OK && tlast >= 0 && u.act != ACT_IDLE)
-                batch_catch_up(u, (unsigned)R.b.w, (int)__builtin_nontemporal_load(pw + i) < 0, i, tend, K.fmA, tab);
+                batch_catch_up(u, (unsigned)R.b.w, (int)__hip_atomic_load(pw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0, i, tend, K.fmA, tab);
             const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
             if (u.act == ACT_DONE) { sumT += timer; ptcS += cold.ptc; fcS += cold.fcnt; }
             ndS += (unsigned)R.b.x;
@@ -634,16 +669,20 @@ __global__ __launch_bounds__(WG_THREADS) void batch_kernel(const TrialDev *__res
     }
 }
 
-size_t batch_kernel_lds_bytes() { return (size_t)bl::END; }
+size_t batch_kernel_lds_bytes(int waves) { return waves == 8 ? (size_t)BL<8>::END : (size_t)BL<16>::END; }
 int batch_max_preambles() { return NPB; }
 int batch_max_rar_window() { return 64; }
 int batch_max_subframes() { return 65000; }
+int batch_max_groups() { return BGROUPS; }
 
-hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, hipStream_t stream) {
-    const size_t lds = batch_kernel_lds_bytes();
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// waves: wavefronts per workgroup — 8: 512 threads, two workgroups (two independent trials) per CU; 16: 1024 threads, one per CU
+hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, int waves, hipStream_t stream) {
+    const size_t lds = batch_kernel_lds_bytes(waves);
+    const void *fn = waves == 8 ? reinterpret_cast<const void *>(&batch_kernel<8>) : reinterpret_cast<const void *>(&batch_kernel<16>);
+    hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(batch_kernel, dim3(ntrials), dim3(WG_THREADS), lds, stream, params);
+    if (waves == 8) hipLaunchKernelGGL(batch_kernel<8>, dim3(ntrials), dim3(512), lds, stream, params);
+    else hipLaunchKernelGGL(batch_kernel<16>, dim3(ntrials), dim3(1024), lds, stream, params);
     return hipGetLastError();
 }
 

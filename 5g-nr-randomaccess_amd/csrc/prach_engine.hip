@@ -54,6 +54,7 @@ struct prach_engine {
     int64_t opt_two_per_cu = 0;    // 1: the streaming regime on the small LDS layout, two 1024-thread workgroups per CU (measured slower: DESIGN.md section 4)
     int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
     int64_t opt_batch = 1;         // 0: one-workgroup-per-trial Philox launches run on the general kernel instead of prach_batch.hip
+    int64_t opt_batch_waves = 0;   // wavefronts per batch-kernel workgroup: 8 (512 threads, two trials per CU), 16 (one), 0 = chosen per launch
     int num_cus = 256;
 };
 
@@ -251,7 +252,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     bool batch = G == 1 && !noma && rng_mode == PRACH_RNG_PHILOX && e->opt_batch && !e->opt_dense && !e->opt_wide_records && maxP <= batch_max_preambles();
     for (int k = 0; k < m && batch; k++) {
         const prach_cfg &c = cfgs[idx[k]];
-        batch = c.maxRarWindow <= batch_max_rar_window() && (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1;
+        batch = c.maxRarWindow <= batch_max_rar_window() && (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups();
     }
     const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G, batch);
     { int rc = ensure_arena(e, LL.end); if (rc != PRACH_OK) return rc; }
@@ -382,7 +383,23 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     else if (batch) {
         e->last.rec_mode = CLUSTER_REC_BATCH;
         e->last.xcd_packed = 0;
-        HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, e->stream));
+        // Workgroup shape (speed only, same results): two 512-thread workgroups = two trials per CU hide each other's barriers and event
+        // record latencies (1000 Beta.c trials: 310 vs 374 ms) — unless the trials are overloaded (more UEs than the UL grants of the
+        // whole trial can serve: an event-dense body, where one 1024-thread workgroup per CU measured 3-7 % faster: 827 vs 854 ms on
+        // config 3), or there are too few trials to fill the CUs twice.
+        int waves = (int)e->opt_batch_waves;
+        if (waves == 0) {
+            double upd_all = 0, upd_over = 0;
+            for (int k = 0; k < m; k++) {
+                const prach_cfg &c = cfgs[idx[k]];
+                const double steps = (double)td[k].stop, capacity = (double)std::max(0, c.nGrantUL - 1) * steps / 5.0;
+                upd_all += (double)c.nUE * steps;
+                if ((double)c.nUE > capacity) upd_over += (double)c.nUE * steps;
+            }
+            waves = (m >= 3 * e->num_cus && upd_over < 0.5 * upd_all) ? 8 : 16;
+        }
+        e->last.workgroups = m;
+        HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, waves, e->stream));
     }
     else if (G > 0) {
         // one workgroup per trial = the streaming regime: 8 + 4 byte hot records, if every subframe number of every trial of
@@ -455,8 +472,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (std::getenv("PRACH_PRINT_STAMPS")) {
             static const char *const nm[24] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "window-rest", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "phaseA",
                                                "w:phaseA|A-barrier", "w:loads", "w:refill", "t:buckets", "-", "-", "-", "-"};
+            static const char *const nmb[24] = {"head", "walk", "walk-barrier", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "-", "-", "-",
+                                                "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_batch.hip
+            const char *const *const names = e->last.rec_mode == CLUSTER_REC_BATCH ? nmb : nm;
             std::fprintf(stderr, "[prach fine stamps/step]");
-            for (int q = 0; q < 20; q++) if (nm[q][0] != '-') std::fprintf(stderr, " %s=%.0f", nm[q], dr.fstamps[q] / (double)dr.steps);
+            for (int q = 0; q < 20; q++) if (names[q][0] != '-') std::fprintf(stderr, " %s=%.0f", names[q], dr.fstamps[q] / (double)dr.steps);
             std::fprintf(stderr, "\n");
         }
         if (dr.status != PRACH_OK) continue;
@@ -682,6 +702,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "batch") == 0) { e->opt_batch = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "batch_waves") == 0) { if (value != 0 && value != 8 && value != 16) return PRACH_ERR_ARG; e->opt_batch_waves = value; return PRACH_OK; }
     if (std::strcmp(key, "xcd_pack") == 0) { e->opt_xcd_pack = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "two_per_cu") == 0) { e->opt_two_per_cu = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;

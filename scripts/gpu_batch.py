@@ -5,6 +5,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 m = g.load_package()
 eng = m.Engine(0)
+for kv in filter(None, os.environ.get("PRACH_ENG_OPTS", "").split(",")):  # e.g. PRACH_ENG_OPTS=batch_waves=16,batch=0
+    eng.set(kv.split("=")[0], int(kv.split("=")[1]))
 times = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 0
@@ -16,8 +18,11 @@ wall = time.time() - t0
 tm = eng.timing()
 upd = sum(c.nUE * r.steps for c, r in zip(cfgs, res))
 print(f"trials={len(cfgs)} variant={variant} G={G} launches={tm.launches} wgs={tm.workgroups} kernel={tm.kernel_ms:.1f}ms wall={wall:.2f}s updates={upd:.3e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} algoGB/s={32*upd/(tm.kernel_ms*1e-3)/1e9:.0f} bad={sum(r.status!=0 for r in res)}")
-own = tm.group_visits * 64 * 8 + tm.event_ues * 40
-print(f"own traffic: {tm.group_visits:.3e} group visits, {tm.event_ues:.3e} event UEs -> {own/1e9:.1f} GB = {own/upd:.2f} B/update = {own/(tm.kernel_ms*1e-3)/1e12:.2f} TB/s")
+# the kernel's OWN bytes.  batch_kernel (rec_mode 4): a visit reads one 4-byte pass word per lane; an event UE reads and writes one 32-byte
+# record, writes its pass word and passes through the queue (4 B in, 4 B out).  The general kernel's 8 + 4 byte form: 8 B per lane and visit, ~40 B per event.
+vis_b, ev_b = (256, 76) if tm.rec_mode == 4 else (512, 40)
+own = tm.group_visits * vis_b + tm.event_ues * ev_b
+print(f"rec_mode={tm.rec_mode} fallback={tm.fallback_trials} own traffic: {tm.group_visits:.3e} group visits x {vis_b} B, {tm.event_ues:.3e} event UEs x {ev_b} B -> {own/1e9:.1f} GB = {own/upd:.2f} B/update = {own/(tm.kernel_ms*1e-3)/1e12:.2f} TB/s")
 if len(sys.argv) > 4:  # compare with the general layout (one workgroup per CU)
     eng.set("two_per_cu", 0)
     res, _ = eng.run_trials(cfgs)

@@ -11,6 +11,8 @@ nUE, variant = int(sys.argv[1]), int(sys.argv[2])
 kw = {k: int(v) for k, v in (a.split("=") for a in sys.argv[3:])}
 seed = kw.pop("seed", 0)
 eng = m.Engine(0)
+for kv in filter(None, os.environ.get("PRACH_ENG_OPTS", "").split(",")):  # e.g. PRACH_ENG_OPTS=batch_waves=16,batch=0
+    eng.set(kv.split("=")[0], int(kv.split("=")[1]))
 eng.set("cluster", 1)
 cfg = m.make_cfg(nUE, variant=variant, rng_mode=m.RNG_PHILOX, seed=seed, **kw)
 (res,), (logs,) = eng.run_trials([cfg], want_logs=True)
