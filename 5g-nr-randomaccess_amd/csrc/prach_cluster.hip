@@ -32,6 +32,7 @@
 // decomposition is DESIGN.md §3.
 #include "prach_device.h"
 #include "prach_device_fn.h"
+#include "prach_ue_body.h"
 #include <limits.h>
 
 namespace prach {
@@ -54,12 +55,9 @@ namespace {
 #define FSTAMP(k) do { } while (0)
 #endif
 
-constexpr int EVC_CALLER = 1, EVC_RESETCAND = 2, EVC_RJOIN = 3, EVC_LEAVER = 4;
+constexpr int EVC_CALLER = UEV_CALLER, EVC_RESETCAND = UEV_RESETCAND, EVC_RJOIN = UEV_RJOIN, EVC_LEAVER = 4;
 constexpr int EVCAPC = 4096; // gathered events per subframe held in LDS
 constexpr int SCAPC = 2048;  // singleton callers per subframe held in LDS
-#ifndef PRACH_PFD
-#define PRACH_PFD 4 // record slots of the streaming pass (compact_phase_a)
-#endif
 constexpr int DEADW = 512;   // dead-group bitmap words (16384 local groups): one run of DEADW / NW words per wavefront, see dead_skip
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
@@ -148,9 +146,6 @@ __device__ __forceinline__ int dead_skip(const CLds &L, const int j, const int b
 // indices: sized by the launch) is addressed through a run-time base.
 constexpr int NPC = 256; // stride of the per-bucket tables (nPreamble <= 254)
 constexpr int LQCAP = CLUSTER_LQCAP; // LDS-resident clusters: event queue = at most every owned UE slot
-// Two layouts: the general one (bucket stride 256, QCAP-entry queue) and the SMALL one of the streaming regime (one workgroup per
-// trial, nPreamble <= 64: bucket stride 64, half the queue, half the gathered-event list) — 61 KB instead of 97 KB, so that TWO
-// 1024-thread workgroups (two independent trials) share a CU: 8 wavefronts per SIMD instead of 4.
 template <int NPC_, int QCAP_, int EVC_, int STG_>
 struct LdsOff {
     static constexpr int GEV = 0;
@@ -177,13 +172,9 @@ struct LdsOff {
     static constexpr int TAIL_L = LCAND + 8 * LCANDCAP;
     static_assert(SIDX % 16 == 0 && TAIL_L % 16 == 0, "16-byte alignment of the event and record arrays");
 };
-constexpr int NPC_S = 64, QCAP_S = QCAP < 4096 ? QCAP : 4096, EVC_S = 2048; // the small layout
-constexpr int NPC_G = NPC, QCAP_G = QCAP, EVCAPC_G = EVCAPC; // (the kernel shadows the three names with its layout's values)
-// stage entries per wavefront: 64 left over from the round before + 64 per record slot of a round (PRACH_PFD slots; the small layout: 2)
-template <int REC_, bool SMALL_, bool GLIBC_> struct CtxT;
+// stage entries per wavefront: 64 left over from the round before + 64 per record slot of a round
+template <int REC_, bool GLIBC_> struct CtxT;
 using lds_off = LdsOff<NPC, QCAP, EVCAPC, 0>;      // (offsets in front of the stage do not depend on it)
-using lds_off_s = LdsOff<NPC_S, QCAP_S, EVC_S, 64 + 64 * 2>;
-static_assert(lds_off_s::TAIL_G <= 80 * 1024, "two workgroups of the small layout per CU");
 
 template <class O>
 __device__ __forceinline__ CLds ccarve(char *smem, bool glibc, int lslots) {
@@ -257,14 +248,14 @@ __device__ __forceinline__ long long wait_granule(const PRACH_G long long *p, un
 //            whole trial (49 groups x 64 UEs x 20 bytes = 63 KB at nUE = 100 000, G = 32): the pass, the event body and the grant
 //            never touch L2 for a record; global memory only sees the cold per-UE fields and the final state
 constexpr int REC_G16 = 0, REC_H8 = 1, REC_L16 = 2;
-template <int REC_, bool SMALL_ = false, bool GLIBC_ = false>
+template <int REC_, bool GLIBC_ = false>
 struct CtxT {
     static constexpr int REC = REC_;
-    static constexpr int QCAPX = SMALL_ ? QCAP_S : QCAP;     // event queue entries
-    static constexpr int EVCX = SMALL_ ? EVC_S : EVCAPC;      // gathered events held in LDS
+    static constexpr int QCAPX = QCAP;     // event queue entries
+    static constexpr int EVCX = EVCAPC;    // gathered events held in LDS
     static constexpr bool H8 = REC_ == REC_H8;   // 8 + 4 byte hot record (one workgroup per trial, streaming)
     static constexpr bool LREC = REC_ == REC_L16; // LDS-resident records
-    static constexpr int PFD = (REC_ == REC_H8 && !SMALL_ && !GLIBC_) ? PRACH_PFD : 2; // record slots of the compacted pass's walk
+    static constexpr int PFD = 2;          // record slots of the compacted pass's walk (the records of a cluster come from L2)
     // the compacted pass collects its event UEs on a per-wavefront stage (64 + 64 per record slot) before it takes queue slots for them —
     // where LDS has room for it: not beside LDS-resident records, not beside the glibc modes' 64 KB of group sums (158.6 of 160 KB already)
     static constexpr bool STAGED = REC_ != REC_L16 && !GLIBC_;
@@ -377,35 +368,18 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
     const int aT = P.aT, nUE = P.nUE;
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
     const int tp = t - 1;
-    const int tmod = t % aT;
-    const FastMod fmP = FM.nP, fmB = FM.backoff, fmA = FM.aT, fm5 = FM.five;
+    const UeK K{P.maxRarWindow, P.maxMsg2, aT, withnoma, FM.nP, FM.backoff, FM.aT, FM.five};
+    ColdGlobal cold{P.ptc, P.ftt, P.stt, P.fcnt};
     bool nd_dirty = false;
     UeState u = unpack(r);
     bool dirty = false;
 
-    // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
+    // ---- deferred outcome of subframe t-1 (prach_ue_body.h ue_apply) ----
     if (!SELECT && u.pend != PEND_NONE) {
         // the compacted pass leaves a UE in steady contention untouched (see compact_phase_a): its record dates from
         // subframe u.tx, since when it has been bumped and has counted one more RAR-window subframe per subframe
         if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; }
-        if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
-            u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
-            if (u.pend == PEND_RESET) u.bo = 0;
-        } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
-            u.tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
-        } else if (u.pend == PEND_RESET) {
-            const int q = u.bo, tmp = u.tx;
-            const int bumped = fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
-            const int x = slot_align_fm(tp + bumped + tmp, fmA);
-            if (x == tp) { u.bo = 0; u.tx = tp + 1; }
-            else { u.tx = x; u.bo = x; }
-        } else if (u.pend == PEND_PASSIVE) {
-            if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
-        } else { // PEND_RJOIN
-            if (lcall[u.pre - 1] > i) u.tx = tp + 1;
-        }
-        u.pend = PEND_NONE;
-        dirty = true;
+        dirty = ue_apply(u, ((unsigned)r.w & PK_GRANT_BIT) != 0u, i, tp, FM.aT, CallTables{fcall, lcall});
     }
     if (FINAL) {
         if (dirty) hot_store_full(C, i, slot, pack(u));
@@ -413,23 +387,13 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
     }
     // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
     if (!SELECT && valid && i >= prevAC) {
-        u.act = ACT_M1; u.tx = t + 1; u.tb = t;
-        P.ftt[i] = t + 1;
+        ue_activate(u, i, t, cold);
         if (MODE == 0 && withnoma) { ndc = 2; nd_dirty = true; }
         dirty = true;
     }
 
-    const bool isM1 = u.act == ACT_M1;
-    const int nb = now_backoff(u.bo, t);
-    const bool firstsel = isM1 && u.pre == 0;
-    const bool contend = isM1 && u.pre != 0 && nb <= 0;
-    const bool expire = contend && (u.rar + 1 >= P.maxRarWindow);
-    const bool reset = expire && u.mrc >= P.maxMsg2;
-    const bool retx = expire && !reset;
-    const bool m3due = u.act == ACT_M3 && u.tx == t;
-    const bool m3first = m3due && u.conn == 0, m3to = m3due && u.conn != 0;
-    const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
-    const bool busy = isM1 || m3due;
+    const UePlan pl = ue_plan(u, t, P.maxRarWindow, P.maxMsg2);
+    const int need = pl.need;
 
     if (COUNT) { // glibc: this group's rand() calls in the UE loop of subframe t (own pre-step state only)
         if (MODE == 1) {
@@ -445,7 +409,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         return;
     }
 
-    if (!__any(busy || dirty)) {
+    if (!__any(pl.busy || dirty)) {
         // nothing happens in this group; retire it for good once every UE in it has finished
         if (jdead >= 0 && __all(i >= nUE || u.act == ACT_DONE) && lane == 0) dead_mark(L, jdead, C.G);
         return;
@@ -477,68 +441,11 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
         if (need > 0) { ndc = k + (unsigned)need; nd_dirty = true; }
     }
 
-    // ---- selectPreamble / requestResourceAllocation on own state ----
-    const int oldp = u.pre - 1;
-    const bool member_pre = isM1 && u.tx == t && u.pre != 0; // matched by a preambleCollision scan right now
-    int evtype = 0, evp = 0, evq = 0;
-    bool eclass = false; // pre-member that leaves its bucket at its own turn without calling on it
-    if (firstsel) { // Beta.c:231-239
-        u.pre = fastmod(d1, fmP) + 1; u.rar = 0; u.mrc = 0; u.bo = 0;
-        P.ptc[i] = 1;
-        if (withnoma) P.fcnt[i] = 0;
-        if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = u.pre - 1; }
-        dirty = true;
-    } else if (isM1 && u.pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
-        if (member_pre) { u.pend = withnoma ? PEND_STAY : PEND_PASSIVE; dirty = true; } // WithNOMA:310 calls anyway
-    } else if (contend) {
-        u.rar++; // Beta.c:245
-        dirty = true;
-        if (reset) { // Beta.c:250-281
-            if (withnoma) { c_contf++; gadd(&P.fcnt[i], 1); }
-            const int newp = fastmod(d1, fmP);
-            const int tmp = fastmod(d2, fmB);
-            u.rar = 0; u.mrc = 0; u.tb = t;
-            P.ptc[i] = 1; P.ftt[i] = t + 1;
-            u.pre = newp + 1;
-            if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
-                u.pend = PEND_RESET; u.tx = tmp; u.bo = oldp;
-                eclass = true;
-                if (tmp == 0 && aT > 1 && tmod == 1) { evtype = EVC_RESETCAND; evp = newp; evq = oldp; }
-            } else {
-                u.tx = slot_align_fm(u.tx + tmp, fmA);
-                u.bo = enc_backoff(u.tx - t, t);
-                if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = newp; }
-            }
-        } else if (retx) { // Beta.c:282-308
-            u.rar = 0; u.mrc++;
-            gadd(&P.ptc[i], 1);
-            const int tmp = fastmod(d1, fmB);
-            u.tx = slot_align_fm(t + tmp, fmA);
-            u.bo = enc_backoff(u.tx - t, t);
-            P.stt[i] = u.tx;
-            if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVC_CALLER; evp = oldp; } // the "late joiner"
-            else if (member_pre) eclass = true;
-        } else if (member_pre) {
-            u.pend = PEND_STAY;
-        }
-    } else if (m3first) { // Beta.c:372-383
-        u.conn = 1;
-        const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
-        if ((double)pf > 0.1) { u.act = ACT_DONE; u.tb = (t - u.tb) + 6; c_succ++; }
-        else { u.conn = 2; u.tx += 48; }
-        dirty = true;
-    } else if (m3to) { // Msg3 timeout, Beta.c:384-410
-        c_contf++;
-        const int tmp = fastmod(d1, fmB);
-        u.tx = slot_align_fm(u.tx + tmp, fm5); // hard-coded accessTime = 5, Beta.c:389
-        u.act = ACT_M1;
-        u.bo = enc_backoff(u.tx - t, t);
-        u.pre = fastmod(d2, fmP) + 1;
-        u.tb = t; u.rar = 0; u.mrc = 0; u.conn = 0;
-        if (withnoma) gadd(&P.fcnt[i], 1);
-        if (u.tx == t) { u.pend = PEND_RJOIN; evtype = EVC_RJOIN; evp = u.pre - 1; }
-        dirty = true;
-    }
+    // ---- selectPreamble / requestResourceAllocation on own state (prach_ue_body.h ue_select) ----
+    const UeOut o = ue_select(u, pl, d1, d2, i, t, t % aT, K, cold, c_succ, c_contf);
+    dirty = dirty || o.dirty;
+    const int oldp = o.oldp, evtype = o.evtype, evp = o.evp;
+    const bool member_pre = o.member_pre, eclass = o.eclass;
 
     // ---- bucket bookkeeping (workgroup-level LDS atomics) ----
     if (member_pre) atomicAdd(&L.hist[oldp], 1);
@@ -552,8 +459,7 @@ __device__ __forceinline__ void ue_step(const TrialG &P, const CLds &L, const CX
             base = __builtin_amdgcn_readlane(base, 0);
             if (evtype != 0) {
                 const int slot = base + __popcll(em & lanemask_lt(lane));
-                const int ispre = (evtype == EVC_CALLER) ? (member_pre && oldp == evp) : (evtype == EVC_RESETCAND ? (evp == evq) : 0);
-                const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
+                const int info = ue_event_info(o);
                 if (C.G == 1) { if (slot < CX::EVCX) L.gev[slot] = make_int2(i, info); }
                 else if (slot < C.evw) st_gr(C.sx, mbev + slot, mk_granule((unsigned)i, (unsigned)info, tag));
             }
@@ -901,11 +807,10 @@ __device__ __forceinline__ void resolve_reset_candidates(const CLds &L, int *fca
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
-template <bool GLIBC, int REC, bool SMALL>
-__global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(const TrialDev *__restrict__ params, const int Garg, const int lslots, const int xpack, const int ntrials) {
+template <bool GLIBC, int REC>
+__global__ __launch_bounds__(WG_THREADS, 4) void cluster_kernel(const TrialDev *__restrict__ params, const int Garg, const int lslots, const int xpack, const int ntrials) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NPC = SMALL ? NPC_S : NPC_G, QCAP = SMALL ? QCAP_S : QCAP_G, EVCAPC = SMALL ? EVC_S : EVCAPC_G;
-    using LO = LdsOff<NPC, QCAP, EVCAPC, CtxT<REC, SMALL, GLIBC>::STG>;
+    using LO = LdsOff<NPC, QCAP, EVCAPC, CtxT<REC, GLIBC>::STG>;
     // the 8 + 4 byte record form is only ever launched with ONE workgroup per trial (the streaming regime): there the cluster size is a
     // compile-time 1 and every exchange / mailbox / pipeline path of this kernel is dead code the compiler drops (half the code, fewer
     // live scalars in the pass)
@@ -926,7 +831,7 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
 
     FastMods FM;
     FM.nP = make_fastmod(P.nP); FM.backoff = make_fastmod(P.backoff); FM.aT = make_fastmod(P.aT); FM.five = make_fastmod(5);
-    CtxT<REC, SMALL, GLIBC> C;
+    CtxT<REC, GLIBC> C;
     C.b = b; C.G = G; C.evw = P.evw; C.mbstride = P.mbstride; C.mbox = P.mbox; C.sx = false;
     C.fmG = make_fastmod(G); C.lrec = L.lrec; C.lnd = L.lnd; C.lcand = L.lcand;
     C.status_word = &L.scal[C_STATUS];
@@ -1431,29 +1336,26 @@ __global__ __launch_bounds__(WG_THREADS, SMALL ? 8 : 4) void cluster_kernel(cons
     }
 }
 
-// small: the streaming layout (one workgroup per trial, Philox, nPreamble <= 64): two workgroups per CU
-size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small, int rec_mode) {
+size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots) {
     (void)nP; // the per-bucket tables have a fixed stride
-    if (small) return (size_t)lds_off_s::TAIL_G;
     if (lslots > 0) return (size_t)lds_off::TAIL_L + (size_t)lslots * 20;
     if (glibc) return (size_t)lds_off::TAIL_G + sizeof(int) * 4 * GSCAP; // (no stage: CtxT::STAGED)
-    return (size_t)lds_off::TAIL_G + sizeof(int) * NW * (rec_mode == REC_H8 ? CtxT<REC_H8, false, false>::STG : CtxT<REC_G16, false, false>::STG);
+    return (size_t)lds_off::TAIL_G + sizeof(int) * NW * CtxT<REC_G16, false>::STG;
 }
-int cluster_small_max_preambles() { return NPC_S; }
 
 using cluster_kernel_t = void (*)(const TrialDev *, int, int, int, int);
-// rec_mode: REC_G16 / REC_H8 (one workgroup per trial: the streaming regime) / REC_L16 (clusters, Philox: LDS-resident records)
-static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode, bool small) {
-    if (rng_mode == PRACH_RNG_GLIBC) return rec_mode == REC_H8 ? cluster_kernel<true, REC_H8, false> : cluster_kernel<true, REC_G16, false>;
-    if (small && rec_mode == REC_H8) return cluster_kernel<false, REC_H8, true>;
-    return rec_mode == REC_L16 ? cluster_kernel<false, REC_L16, false> : (rec_mode == REC_H8 ? cluster_kernel<false, REC_H8, false> : cluster_kernel<false, REC_G16, false>);
+// rec_mode: REC_G16 / REC_H8 (the reference's rand() stream with one workgroup per trial) / REC_L16 (clusters, Philox: LDS-resident records).
+// Philox with one workgroup per trial is prach_batch.hip's; outside its limits (nPreamble > 64, ...) the 16-byte form runs here.
+static cluster_kernel_t pick_cluster_kernel(int rng_mode, int rec_mode) {
+    if (rng_mode == PRACH_RNG_GLIBC) return rec_mode == REC_H8 ? cluster_kernel<true, REC_H8> : cluster_kernel<true, REC_G16>;
+    return rec_mode == REC_L16 ? cluster_kernel<false, REC_L16> : cluster_kernel<false, REC_G16>;
 }
 
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, int xpack, hipStream_t stream) {
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int xpack, hipStream_t stream) {
     if (rec_mode != REC_L16) lslots = 0;
-    small = small && rec_mode == REC_H8 && rng_mode != PRACH_RNG_GLIBC;
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, small, rec_mode);
-    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode, small);
+    if (rec_mode == REC_H8 && rng_mode != PRACH_RNG_GLIBC) rec_mode = REC_G16;
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode);
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
     if (rec_mode == REC_H8 || G <= 1) xpack = 0;
@@ -1465,8 +1367,9 @@ hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int
 // workgroups of this kernel (with its dynamic LDS) the runtime admits per CU: what a cooperative launch would be checked against
 int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots) {
     if (rec_mode != REC_L16) lslots = 0;
-    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots, false, rec_mode);
-    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode, false);
+    if (rec_mode == REC_H8 && rng_mode != PRACH_RNG_GLIBC) rec_mode = REC_G16;
+    const size_t lds = cluster_kernel_lds_bytes(maxP, rng_mode == PRACH_RNG_GLIBC, lslots);
+    const cluster_kernel_t fn = pick_cluster_kernel(rng_mode, rec_mode);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;

@@ -91,10 +91,9 @@ constexpr int RCCAP = 256;          // reset-cycle re-join candidates per subfra
 
 size_t trial_kernel_lds_bytes(int nP);
 hipError_t launch_trial_kernel(const TrialDev *params, int ntrials, int rng_mode, int maxP, hipStream_t stream);
-size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots, bool small = false, int rec_mode = 0);
-int cluster_small_max_preambles(); // the streaming layout (two workgroups per CU) holds this many preambles
+size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots);
 // rec_mode: where / how a trial's hot records are kept (prach_cluster.hip): 0 global 16 B, 1 global 8 + 4 B (one workgroup per
-// trial), 2 LDS-resident (clusters, Philox; lslots = owned UE slots per workgroup, the launch's maximum)
+// trial, the reference's rand() stream), 2 LDS-resident (clusters, Philox; lslots = owned UE slots per workgroup, the launch's maximum)
 constexpr int CLUSTER_REC_G16 = 0, CLUSTER_REC_H8 = 1, CLUSTER_REC_L16 = 2;
 constexpr int CLUSTER_EVW = 512;   // special-event granules per cluster mailbox and subframe
 constexpr int CLUSTER_REC_LFAST = 3; // prach_lcluster.hip: the lean LDS-resident kernel (Philox clusters, nPreamble <= 64)
@@ -104,7 +103,7 @@ hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, in
 int lcluster_kernel_blocks_per_cu(int lslots);
 constexpr int CLUSTER_LQCAP = 4096; // LDS-resident clusters: owned UE slots per workgroup at most (= the event queue)
 constexpr size_t CLUSTER_LDS_LIMIT = 160 * 1024; // LDS per CU (MI355X_MICROARCH.md): one LDS-resident cluster workgroup per CU
-hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int small, int xpack, hipStream_t stream);
+hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int xpack, hipStream_t stream);
 int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots); // occupancy query for the kernel and its dynamic LDS size
 constexpr int CLUSTER_REC_BATCH = 4; // prach_batch.hip: one workgroup per trial, 4-byte pass words + 32-byte event records (Philox)
 size_t batch_kernel_lds_bytes(int waves);

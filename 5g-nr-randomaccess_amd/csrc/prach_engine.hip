@@ -51,7 +51,6 @@ struct prach_engine {
 #endif
     int64_t opt_xcd_pack = 1;      // 1: lean clusters are launched XCD-packed (a cluster per XCD; granules stay in that XCD's L2 once verified)
     bool pack_off = false;         // (set for the rerun of a packed launch that timed out)
-    int64_t opt_two_per_cu = 0;    // 1: the streaming regime on the small LDS layout, two 1024-thread workgroups per CU (measured slower: DESIGN.md section 4)
     int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
     int64_t opt_batch = 1;         // 0: one-workgroup-per-trial Philox launches run on the general kernel instead of prach_batch.hip
     int64_t opt_batch_waves = 0;   // wavefronts per batch-kernel workgroup: 8 (512 threads, two trials per CU), 16 (one), 0 = chosen per launch
@@ -402,9 +401,9 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, waves, e->stream));
     }
     else if (G > 0) {
-        // one workgroup per trial = the streaming regime: 8 + 4 byte hot records, if every subframe number of every trial of
-        // the launch fits 16 bits (txTime <= t + 59 + backoff + accessTime)
-        bool compact = G == 1 && !e->opt_wide_records;
+        // one workgroup per trial in the reference's rand() stream: 8 + 4 byte hot records, if every subframe number of every trial of
+        // the launch fits 16 bits (txTime <= t + 59 + backoff + accessTime).  (Philox with one workgroup per trial is the batch kernel's.)
+        bool compact = G == 1 && !e->opt_wide_records && rng_mode == PRACH_RNG_GLIBC;
         for (int k = 0; k < m && compact; k++) {
             const prach_cfg &c = cfgs[idx[k]];
             compact = (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 64 < 63000;
@@ -418,9 +417,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         e->last.xcd_packed = xpack;
         if (rec_mode == CLUSTER_REC_LFAST) HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, xpack, e->stream));
         else {
-            // the streaming layout (two 1024-thread workgroups = two independent trials per CU): one workgroup per trial, Philox, <= 64 preambles
-            const int small = rec_mode == CLUSTER_REC_H8 && rng_mode == PRACH_RNG_PHILOX && maxP <= cluster_small_max_preambles() && e->opt_two_per_cu;
-            HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, small, xpack, e->stream));
+            HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, xpack, e->stream));
         }
     }
     else HIPCHK(launch_trial_kernel(reinterpret_cast<const TrialDev *>(A), m, rng_mode, maxP, e->stream));
@@ -704,7 +701,6 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "batch") == 0) { e->opt_batch = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "batch_waves") == 0) { if (value != 0 && value != 8 && value != 16) return PRACH_ERR_ARG; e->opt_batch_waves = value; return PRACH_OK; }
     if (std::strcmp(key, "xcd_pack") == 0) { e->opt_xcd_pack = value != 0; return PRACH_OK; }
-    if (std::strcmp(key, "two_per_cu") == 0) { e->opt_two_per_cu = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
 }
 

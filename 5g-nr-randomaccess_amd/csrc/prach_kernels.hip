@@ -23,6 +23,7 @@
 // addressed through an index-ordered prefix sum of per-UE draw counts (bit-exact vs the reference).
 #include "prach_device.h"
 #include "prach_device_fn.h"
+#include "prach_ue_body.h"
 #include <limits.h>
 
 namespace prach {
@@ -89,6 +90,8 @@ __device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int
     const int nP = P.nP, aT = P.aT;
     const FastMod fmP = make_fastmod(nP), fmB = make_fastmod(P.backoff), fmA = make_fastmod(aT), fm5 = make_fastmod(5);
     const bool withnoma = P.variant == PRACH_VARIANT_WITHNOMA_C;
+    const UeK K{P.maxRarWindow, P.maxMsg2, aT, withnoma, fmP, fmB, fmA, fm5};
+    ColdGlobal cold{P.ptc, P.ftt, P.stt, P.fcnt};
     const int groups = (activeCheck + 63) >> 6;
     const int gper = (groups + NW - 1) / NW;
     const int g0 = w * gper, g1 = min(groups, g0 + gper);
@@ -108,78 +111,33 @@ __device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int
         const bool valid = i < activeCheck;
         int4 r = make_int4(-1, 0, 0, 0);
         if (valid) r = load_rec(&P.rec[i]);
-        int tx = r.x, tb = r.y, bo = r.z;
-        int act = (r.w >> PK_ACT_SHIFT) & 3, conn = (r.w >> PK_CONN_SHIFT) & 3, pre = (r.w >> PK_PRE_SHIFT) & 0xff,
-            rar = (r.w >> PK_RAR_SHIFT) & 0xff, mrc = (r.w >> PK_MRC_SHIFT) & 0xff, pend = (r.w >> PK_PEND_SHIFT) & 7;
+        UeState u = unpack(r);
         bool dirty = false;
 
         if (MODE != 2) {
-            // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
-            if (pend != PEND_NONE) {
-                if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
-                    act = ACT_M3; tx = tp + 11; conn = 0;
-                    if (pend == PEND_RESET) bo = 0;
-                } else if (pend == PEND_STAY || pend == PEND_CALLER) {
-                    tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
-                } else if (pend == PEND_RESET) {
-                    const int q = bo, tmp = tx;
-                    const int bumped = L.fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
-                    const int x = slot_align_fm(tp + bumped + tmp, fmA);
-                    if (x == tp) { bo = 0; tx = tp + 1; } // re-joined and called, no grant
-                    else { tx = x; bo = x; }
-                } else if (pend == PEND_PASSIVE) {
-                    if (L.fcall[pre - 1] != INT_MAX) tx = tp + 1;
-                } else { // PEND_RJOIN
-                    if (L.lcall[pre - 1] > i) tx = tp + 1;
-                }
-                pend = PEND_NONE;
-                dirty = true;
-            }
+            // ---- deferred outcome of subframe t-1 (prach_ue_body.h ue_apply) ----
+            dirty = ue_apply(u, ((unsigned)r.w & PK_GRANT_BIT) != 0u, i, tp, fmA, CallTables{L.fcall, L.lcall});
             // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
             if (MODE != 3 && valid && i >= prevAC) {
-                act = ACT_M1; tx = t + 1; tb = t;
-                P.ftt[i] = t + 1;
+                ue_activate(u, i, t, cold);
                 if (!GLIBC && withnoma) P.nd[i] = 2;
                 dirty = true;
             }
         }
 
         // what this UE will do in subframe t, from its own state
-        const bool isM1 = act == ACT_M1;
-        const int nb = now_backoff(bo, t);
-        const bool firstsel = isM1 && pre == 0;
-        const bool contend = isM1 && pre != 0 && nb <= 0;
-        const bool expire = contend && (rar + 1 >= P.maxRarWindow);
-        const bool reset = expire && mrc >= P.maxMsg2;
-        const bool retx = expire && !reset;
-        const bool m3due = act == ACT_M3 && tx == t;
-        const bool m3first = m3due && conn == 0, m3to = m3due && conn != 0;
-        const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
+        const UePlan pl = ue_plan(u, t, P.maxRarWindow, P.maxMsg2);
+        const int need = pl.need;
 
-        if (MODE == 1) {
-            wdraw += (unsigned)need;
-            if (dirty) {
-                r.x = tx; r.y = tb; r.z = bo;
-                r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
-                      (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
-                store_rec(&P.rec[i], r);
-            }
-            continue;
-        }
-        if (MODE == 3) {
-            if (dirty) {
-                r.x = tx; r.y = tb; r.z = bo;
-                r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
-                      (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
-                store_rec(&P.rec[i], r);
-            }
+        if (MODE == 1 || MODE == 3) {
+            if (MODE == 1) wdraw += (unsigned)need;
+            if (dirty) store_rec(&P.rec[i], pack(u));
             continue;
         }
 
         // nothing to do for the whole wavefront?  (waiting / finished / not yet arrived UEs)
-        const bool busy = isM1 || m3due;
-        if (!__any(busy || dirty)) {
-            if (g < DEADW_T * 32 && __all(i >= P.nUE || act == ACT_DONE) && lane == 0) atomicOr(&L.dead[g >> 5], 1u << (g & 31));
+        if (!__any(pl.busy || dirty)) {
+            if (g < DEADW_T * 32 && __all(i >= P.nUE || u.act == ACT_DONE) && lane == 0) atomicOr(&L.dead[g >> 5], 1u << (g & 31));
             continue;
         }
 
@@ -202,69 +160,15 @@ __device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int
             }
         }
 
-        // ---- selectPreamble / requestResourceAllocation on own state ----
-        const int oldp = pre - 1;
-        const bool member_pre = isM1 && tx == t && pre != 0; // matched by a preambleCollision scan right now
-        int evtype = 0, evp = 0, evq = 0;
-        if (firstsel) { // Beta.c:231-239
-            pre = fastmod(d1, fmP) + 1; rar = 0; mrc = 0; bo = 0;
-            P.ptc[i] = 1;
-            if (withnoma) P.fcnt[i] = 0;
-            if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = pre - 1; }
-            dirty = true;
-        } else if (isM1 && pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
-            if (member_pre) {
-                if (withnoma) pend = PEND_STAY; // WithNOMA:310 calls whatever nowBackoff is
-                else { pend = PEND_PASSIVE; evtype = EV_PASSIVE; evp = oldp; }
-                dirty = true;
-            }
-        } else if (contend) {
-            rar++; // Beta.c:245
-            dirty = true;
-            if (reset) { // Beta.c:250-281
-                if (withnoma) { c_contf++; P.fcnt[i] = P.fcnt[i] + 1; }
-                const int newp = fastmod(d1, fmP);
-                const int tmp = fastmod(d2, fmB);
-                rar = 0; mrc = 0; tb = t;
-                P.ptc[i] = 1; P.ftt[i] = t + 1;
-                pre = newp + 1;
-                if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
-                    pend = PEND_RESET; tx = tmp; bo = oldp;
-                    if (tmp == 0 && aT > 1 && t % aT == 1) { evtype = EV_RESETCAND; evp = newp; evq = oldp; }
-                } else {
-                    tx = slot_align_fm(tx + tmp, fmA);
-                    bo = enc_backoff(tx - t, t);
-                    if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = newp; }
-                }
-            } else if (retx) { // Beta.c:282-308
-                rar = 0; mrc++;
-                P.ptc[i] = P.ptc[i] + 1;
-                const int tmp = fastmod(d1, fmB);
-                tx = slot_align_fm(t + tmp, fmA);
-                bo = enc_backoff(tx - t, t);
-                P.stt[i] = tx;
-                if (tx == t) { pend = PEND_CALLER; evtype = EV_CALLER; evp = oldp; } // the "late joiner"
-            } else if (member_pre) {
-                pend = PEND_STAY;
-            }
-        } else if (m3first) { // Beta.c:372-383
-            conn = 1;
-            const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
-            if ((double)pf > 0.1) { act = ACT_DONE; tb = (t - tb) + 6; c_succ++; }
-            else { conn = 2; tx += 48; }
-            dirty = true;
-        } else if (m3to) { // Msg3 timeout, Beta.c:384-410
-            c_contf++;
-            const int tmp = fastmod(d1, fmB);
-            tx = slot_align_fm(tx + tmp, fm5); // hard-coded accessTime = 5, Beta.c:389
-            act = ACT_M1;
-            bo = enc_backoff(tx - t, t);
-            pre = fastmod(d2, fmP) + 1;
-            tb = t; rar = 0; mrc = 0; conn = 0;
-            if (withnoma) P.fcnt[i] = P.fcnt[i] + 1;
-            if (tx == t) { pend = PEND_RJOIN; evtype = EV_RJOIN; evp = pre - 1; }
-            dirty = true;
-        }
+        // ---- selectPreamble / requestResourceAllocation on own state (prach_ue_body.h ue_select) ----
+        const UeOut o = ue_select(u, pl, d1, d2, i, t, t % aT, K, cold, c_succ, c_contf);
+        dirty = dirty || o.dirty;
+        const int oldp = o.oldp, evq = o.evq;
+        const bool member_pre = o.member_pre;
+        // (this kernel's event list format: EV_* of prach_device.h; a passive member is an ordered event here)
+        const int evtype = o.passive ? EV_PASSIVE : (o.evtype == UEV_CALLER ? EV_CALLER : (o.evtype == UEV_RESETCAND ? EV_RESETCAND : (o.evtype == UEV_RJOIN ? EV_RJOIN : 0)));
+        const int evp = o.passive ? oldp : o.evp;
+        const int pend = u.pend;
 
         // ---- bucket bookkeeping for the resolver (wavefront-level) ----
         const bool stay = pend == PEND_STAY;
@@ -304,12 +208,7 @@ __device__ __forceinline__ void ue_pass(const TrialG &P, const Lds &L, const int
                 evn += __popcll(em);
             }
         }
-        if (dirty) {
-            r.x = tx; r.y = tb; r.z = bo;
-            r.w = (act << PK_ACT_SHIFT) | (conn << PK_CONN_SHIFT) | (pre << PK_PRE_SHIFT) | (rar << PK_RAR_SHIFT) |
-                  (mrc << PK_MRC_SHIFT) | (pend << PK_PEND_SHIFT);
-            store_rec(&P.rec[i], r);
-        }
+        if (dirty) store_rec(&P.rec[i], pack(u));
     }
 
     if (MODE == 1) {

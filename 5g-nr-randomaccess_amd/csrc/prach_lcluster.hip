@@ -26,6 +26,7 @@
 // Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351.
 #include "prach_device.h"
 #include "prach_device_fn.h"
+#include "prach_ue_body.h"
 #include <limits.h>
 
 namespace prach {
@@ -61,7 +62,7 @@ constexpr int LEPF = 32;     // event granules of every mailbox fetched together
 constexpr int LRQ = 1024;    // UEs per subframe whose next two Philox draws are recomputed ahead (more: drawn in place)
 constexpr unsigned ND_READY = 0x80000000u; // lnd[slot] bit 31: ldraw[slot] holds draws nd, nd + 1 of this UE
 constexpr unsigned LSPIN = 1u << 22;
-constexpr int EVL_CALLER = 1, EVL_RESETCAND = 2, EVL_RJOIN = 3, EVL_LEAVER = 4; // (= prach_cluster.hip's EVC_*)
+constexpr int EVL_CALLER = UEV_CALLER, EVL_RESETCAND = UEV_RESETCAND, EVL_RJOIN = UEV_RJOIN, EVL_LEAVER = 4; // (= prach_cluster.hip's EVC_*)
 
 // scalars in LDS
 enum { S_NSUCC = 0, S_COLL, S_TXOP, S_CONTF, S_NS, S_NRC, S_NRJ, S_NEV = 8, S_NCAND /* = S_NEV + 1: read as a pair; both [2] by subframe parity (+ 2): slots 8..11 */, S_PTC = 13, S_FC, S_SUMT = 16,
@@ -160,56 +161,26 @@ __device__ __forceinline__ bool l_light(const unsigned pk, const int rx, const i
 __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsigned *lnd, const int2 *ldraw, const int pc, const int fb, const int t, const int prevAC,
                                        PRACH_G long long *mbev, const unsigned tag, const int lane, const int i, const int slot, const bool valid, const int4 r,
                                        unsigned ndc, int &c_succ, int &c_contf) {
-    const int aT = K.aT, nUE = K.nUE;
-    const bool withnoma = K.withnoma;
+    const int nUE = K.nUE;
     const int tp = t - 1;
     const int tmod = fastmod(t, K.fmA);
-    const int *const fcall = LI(lo::FCALL + fb), *const lcall = LI(lo::LCALL + fb);
     int *const hist = LI(lo::PAR + pc + lo::P_HIST), *const mloc = LI(lo::PAR + pc + lo::P_MLOC), *const candn = LI(lo::PAR + pc + lo::P_CANDN);
+    const UeK UK{K.maxRar, K.maxMsg2, K.aT, K.withnoma, K.fmP, K.fmB, K.fmA, K.fm5};
+    ColdGlobal cold{K.ptc, K.ftt, K.stt, K.fcnt};
     bool nd_dirty = false, dirty = false;
     bool rdy = (ndc & ND_READY) != 0u;
     ndc &= ~ND_READY;
     UeState u = unpack(r);
 
-    // ---- deferred outcome of subframe t-1 (preambleCollision's side effects, Beta.c:332-366) ----
+    // ---- deferred outcome of subframe t-1 (prach_ue_body.h ue_apply) ----
     if (u.pend != PEND_NONE) {
         if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; } // (the record dates from subframe u.tx: compact phase A)
-        if ((unsigned)r.w & PK_GRANT_BIT) { // singleton caller that got an UL grant (Beta.c:338-343)
-            u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
-            if (u.pend == PEND_RESET) u.bo = 0;
-        } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
-            u.tx = tp + 1; // bumped, collided, or singleton without a grant (Beta.c:346,358)
-        } else if (u.pend == PEND_RESET) {
-            const int q = u.bo, tmp = u.tx;
-            const int bumped = fcall[q] < i ? 1 : 0; // stale txTime seen by Beta.c:266
-            const int x = slot_align_fm(tp + bumped + tmp, K.fmA);
-            if (x == tp) { u.bo = 0; u.tx = tp + 1; }
-            else { u.tx = x; u.bo = x; }
-        } else if (u.pend == PEND_PASSIVE) {
-            if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
-        } else { // PEND_RJOIN
-            if (lcall[u.pre - 1] > i) u.tx = tp + 1;
-        }
-        u.pend = PEND_NONE;
-        dirty = true;
+        dirty = ue_apply(u, ((unsigned)r.w & PK_GRANT_BIT) != 0u, i, tp, K.fmA, CallTables{LI(lo::FCALL + fb), LI(lo::LCALL + fb)});
     }
-    // ---- activation (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice) ----
-    if (valid && i >= prevAC) {
-        u.act = ACT_M1; u.tx = t + 1; u.tb = t;
-        K.ftt[i] = t + 1;
-        // (activateUEs' two draws, WithNOMA:393-394, are never looked at: a WithNOMA UE's draw index STARTS at 2)
-        dirty = true;
-    }
-    const bool isM1 = u.act == ACT_M1;
-    const int nb = now_backoff(u.bo, t);
-    const bool firstsel = isM1 && u.pre == 0;
-    const bool contend = isM1 && u.pre != 0 && nb <= 0;
-    const bool expire = contend && (u.rar + 1 >= K.maxRar);
-    const bool reset = expire && u.mrc >= K.maxMsg2;
-    const bool retx = expire && !reset;
-    const bool m3due = u.act == ACT_M3 && u.tx == t;
-    const bool m3first = m3due && u.conn == 0, m3to = m3due && u.conn != 0;
-    const int need = (firstsel || retx || m3first) ? 1 : ((reset || m3to) ? 2 : 0);
+    // ---- activation (Beta.c:136-146; activateUEs' two draws, WithNOMA:393-394, are never looked at: a WithNOMA UE's draw index STARTS at 2) ----
+    if (valid && i >= prevAC) { ue_activate(u, i, t, cold); dirty = true; }
+    const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
+    const int need = pl.need;
 
     // The next two draws of a UE (Philox counters nd, nd + 1) were computed AHEAD, off the subframe's critical chain (refill in
     // the exchange window), and wait in LDS; a UE whose refill did not fit the list draws in place.
@@ -225,68 +196,11 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
         if (need > 0) { ndc = k + (unsigned)need; nd_dirty = true; rdy = false; } // (its refill is listed below)
     }
 
-    // ---- selectPreamble / requestResourceAllocation on own state ----
-    const int oldp = u.pre - 1;
-    const bool member_pre = isM1 && u.tx == t && u.pre != 0; // matched by a preambleCollision scan right now
-    int evtype = 0, evp = 0, evq = 0;
-    bool eclass = false; // pre-member that leaves its bucket at its own turn without calling on it
-    if (firstsel) { // Beta.c:231-239
-        u.pre = fastmod(d1, K.fmP) + 1; u.rar = 0; u.mrc = 0; u.bo = 0;
-        K.ptc[i] = 1;
-        if (withnoma) K.fcnt[i] = 0;
-        if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVL_CALLER; evp = u.pre - 1; }
-        dirty = true;
-    } else if (isM1 && u.pre != 0 && nb > 0) { // in backoff (Beta.c:243 false)
-        if (member_pre) { u.pend = withnoma ? PEND_STAY : PEND_PASSIVE; dirty = true; } // WithNOMA:310 calls anyway
-    } else if (contend) {
-        u.rar++; // Beta.c:245
-        dirty = true;
-        if (reset) { // Beta.c:250-281
-            if (withnoma) { c_contf++; gadd(&K.fcnt[i], 1); }
-            const int newp = fastmod(d1, K.fmP);
-            const int tmp = fastmod(d2, K.fmB);
-            u.rar = 0; u.mrc = 0; u.tb = t;
-            K.ptc[i] = 1; K.ftt[i] = t + 1;
-            u.pre = newp + 1;
-            if (member_pre) { // txTime depends on whether an earlier caller bumped this UE: defer
-                u.pend = PEND_RESET; u.tx = tmp; u.bo = oldp;
-                eclass = true;
-                if (tmp == 0 && aT > 1 && tmod == 1) { evtype = EVL_RESETCAND; evp = newp; evq = oldp; }
-            } else {
-                u.tx = slot_align_fm(u.tx + tmp, K.fmA);
-                u.bo = enc_backoff(u.tx - t, t);
-                if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVL_CALLER; evp = newp; }
-            }
-        } else if (retx) { // Beta.c:282-308
-            u.rar = 0; u.mrc++;
-            gadd(&K.ptc[i], 1);
-            const int tmp = fastmod(d1, K.fmB);
-            u.tx = slot_align_fm(t + tmp, K.fmA);
-            u.bo = enc_backoff(u.tx - t, t);
-            K.stt[i] = u.tx;
-            if (u.tx == t) { u.pend = PEND_CALLER; evtype = EVL_CALLER; evp = oldp; } // the "late joiner"
-            else if (member_pre) eclass = true;
-        } else if (member_pre) {
-            u.pend = PEND_STAY;
-        }
-    } else if (m3first) { // Beta.c:372-383
-        u.conn = 1;
-        const float pf = (float)d1 / (float)2147483647; // (float)RAND_MAX == 2^31
-        if ((double)pf > 0.1) { u.act = ACT_DONE; u.tb = (t - u.tb) + 6; c_succ++; }
-        else { u.conn = 2; u.tx += 48; }
-        dirty = true;
-    } else if (m3to) { // Msg3 timeout, Beta.c:384-410
-        c_contf++;
-        const int tmp = fastmod(d1, K.fmB);
-        u.tx = slot_align_fm(u.tx + tmp, K.fm5); // hard-coded accessTime = 5, Beta.c:389
-        u.act = ACT_M1;
-        u.bo = enc_backoff(u.tx - t, t);
-        u.pre = fastmod(d2, K.fmP) + 1;
-        u.tb = t; u.rar = 0; u.mrc = 0; u.conn = 0;
-        if (withnoma) gadd(&K.fcnt[i], 1);
-        if (u.tx == t) { u.pend = PEND_RJOIN; evtype = EVL_RJOIN; evp = u.pre - 1; }
-        dirty = true;
-    }
+    // ---- selectPreamble / requestResourceAllocation on own state (prach_ue_body.h ue_select) ----
+    const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, UK, cold, c_succ, c_contf);
+    dirty = dirty || o.dirty;
+    const int oldp = o.oldp, evtype = o.evtype, evp = o.evp;
+    const bool member_pre = o.member_pre, eclass = o.eclass;
 
     // ---- bucket bookkeeping (workgroup-level LDS atomics) ----
     if (member_pre) atomicAdd(&hist[oldp], 1);
@@ -306,8 +220,7 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
             b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd); b_rq = __builtin_amdgcn_readfirstlane(b_rq);
             if (evtype != 0) {
                 const int es = b_ev + __popcll(em & lanemask_lt(lane));
-                const int ispre = (evtype == EVL_CALLER) ? (member_pre && oldp == evp) : (evtype == EVL_RESETCAND ? (evp == evq) : 0);
-                const int info = evtype | (ispre << 3) | (evp << 4) | (evq << 12);
+                const int info = ue_event_info(o);
                 if (es < CLUSTER_EVW) lstx(K.sx, mbev + es, lmk((unsigned)i, (unsigned)info, tag));
             }
             if (eclass) {
@@ -970,25 +883,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             const int4 r = lrec[x];
             UeState u = unpack(r);
             if (status == PRACH_OK && tlast >= 0 && u.pend != PEND_NONE) { // (as in l_step, with tp = tlast)
-                const int tp = tlast;
-                if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; }
-                if ((unsigned)r.w & PK_GRANT_BIT) {
-                    u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
-                    if (u.pend == PEND_RESET) u.bo = 0;
-                } else if (u.pend == PEND_STAY || u.pend == PEND_CALLER) {
-                    u.tx = tp + 1;
-                } else if (u.pend == PEND_RESET) {
-                    const int q = u.bo, tmp = u.tx;
-                    const int bumped = fcall[q] < i ? 1 : 0;
-                    const int xx = slot_align_fm(tp + bumped + tmp, K.fmA);
-                    if (xx == tp) { u.bo = 0; u.tx = tp + 1; }
-                    else { u.tx = xx; u.bo = xx; }
-                } else if (u.pend == PEND_PASSIVE) {
-                    if (fcall[u.pre - 1] != INT_MAX) u.tx = tp + 1;
-                } else {
-                    if (lcall[u.pre - 1] > i) u.tx = tp + 1;
-                }
-                u.pend = PEND_NONE;
+                if (u.pend == PEND_STAY) { u.rar += tlast - u.tx; u.tx = tlast; }
+                ue_apply(u, ((unsigned)r.w & PK_GRANT_BIT) != 0u, i, tlast, K.fmA, CallTables{fcall, lcall});
             }
             const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
             const int ptc = K.ptc[i], fc = K.fcnt[i];

@@ -23,8 +23,3 @@ print(f"trials={len(cfgs)} variant={variant} G={G} launches={tm.launches} wgs={t
 vis_b, ev_b = (256, 76) if tm.rec_mode == 4 else (512, 40)
 own = tm.group_visits * vis_b + tm.event_ues * ev_b
 print(f"rec_mode={tm.rec_mode} fallback={tm.fallback_trials} own traffic: {tm.group_visits:.3e} group visits x {vis_b} B, {tm.event_ues:.3e} event UEs x {ev_b} B -> {own/1e9:.1f} GB = {own/upd:.2f} B/update = {own/(tm.kernel_ms*1e-3)/1e12:.2f} TB/s")
-if len(sys.argv) > 4:  # compare with the general layout (one workgroup per CU)
-    eng.set("two_per_cu", 0)
-    res, _ = eng.run_trials(cfgs)
-    tm = eng.timing()
-    print(f"two_per_cu=0: kernel={tm.kernel_ms:.1f}ms kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e}")
