@@ -53,7 +53,8 @@ class PrachTiming(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("total_ms", C.c_double),
                 ("launches", C.c_int32), ("workgroups", C.c_int32), ("updates", C.c_uint64),
                 ("cluster_size", C.c_int32), ("resident_limit", C.c_int32), ("fallback_trials", C.c_int32), ("spin_timeouts", C.c_int32),
-                ("rec_mode", C.c_int32), ("xcd_packed", C.c_int32), ("group_visits", C.c_uint64), ("event_ues", C.c_uint64)]
+                ("rec_mode", C.c_int32), ("xcd_packed", C.c_int32), ("group_visits", C.c_uint64), ("event_ues", C.c_uint64),
+                ("trial_kernel_reruns", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class PrachError(RuntimeError):

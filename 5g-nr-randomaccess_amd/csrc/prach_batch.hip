@@ -18,7 +18,7 @@
 //     first / second TxTime — is ONE 32-byte record, read and written only by the event body: an event is one 32-byte sector
 //     in, one out, plus the pass word (the general kernel touched up to seven arrays per event; profiles/r03_config3.md).
 //   * The event body is prach_ue_body.h (shared with every other kernel); the resolver is prach_cluster.hip's for one workgroup.
-//   * No per-subframe queue capacity: the event queue continues in global memory behind its LDS part.
+//   * No per-subframe capacity on the event queue or on the resolver's event list: both continue in global memory behind their LDS part.
 // Limits (the engine falls back to prach::cluster_kernel): Philox draws, nPreamble <= 64, maxRarWindow <= 64, < 65 000 subframes.
 // Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351; decomposition: DESIGN.md section 3.
 #include "prach_device.h"
@@ -182,6 +182,11 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     const PRACH_G int *const sched = (const PRACH_G int *)PD->sched;
     int *const scal = BI(bl::SCAL);
     int2 *const gev = BI2(bl::GEV);
+    // the event list of a subframe: BEV entries in LDS, the rest (event storms of extreme parameter sets) in global memory — no capacity
+    PRACH_G v2i_t *const evov = (PRACH_G v2i_t *)PD->evov;
+    auto ev_get = [&](const int k) -> int2 { if (k < BEV) return gev[k]; const v2i_t v = evov[k - BEV]; return make_int2(v.x, v.y); };
+    auto ev_set = [&](const int k, const int a, const int b) { if (k < BEV) gev[k] = make_int2(a, b); else store_i2(&evov[k - BEV], a, b); };
+    auto ev_kill = [&](const int k) { if (k < BEV) gev[k].y = 0; else evov[k - BEV].y = 0; };
     int *const queue = BI(bl::QUEUE);
     unsigned short *const lst = reinterpret_cast<unsigned short *>(smem + bl::LIST) + w * (BLCAP + 16); // this wavefront's live groups
     int *const histx = BI(bl::HISTX), *const mlocx = BI(bl::MLOCX);
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
     int nlive = 0; // entries of this wavefront's list (wave-uniform)
+    int why = 0;   // which per-subframe capacity ended the trial (reported)
     unsigned long long steps = 0;
     int status = (nP > NPB || K.maxRar > 64 || stop > 65000 || totgroups > BGROUPS || nUE >= (1 << 20)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
 #ifdef PRACH_STAMPS
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                         b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
                         if (o.evtype != UEV_NONE) {
                             const int es = b_ev + __popcll(em & lanemask_lt(lane));
-                            if (es < BEV) gev[es] = make_int2(i, ue_event_info(o));
+                            ev_set(es, i, ue_event_info(o));
                         }
                         if (o.eclass) store_i2(&cand[b_cd + __popcll(cm & lanemask_lt(lane))], i, o.oldp);
                     }
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 const v2i_t c = cand[k];
                 if (c.x < mlocx[c.y]) {
                     const int es = atomicAdd(&scal[B_NEV], 1);
-                    if (es < BEV) gev[es] = make_int2(c.x, EVB_LEAVER | (c.y << 4));
+                    ev_set(es, c.x, EVB_LEAVER | (c.y << 4));
                 }
             }
             if (tid < NPB) { lcallB[tid] = -1; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; }
@@ -430,17 +436,16 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             BI(bl::TOTAL)[tid] = BI(bl::HISTX)[tid]; fcallA[tid] = BI(bl::MLOCX)[tid];
             BI(bl::HISTX)[tid] = 0; BI(bl::MLOCX)[tid] = INT_MAX;
         }
-        if (N > BEV) { status = PRACH_ERR_INTERNAL; time_exit = t; break; } // engine: exact rerun on trial_kernel
         __syncthreads(); // S3
         if (tid == 0) { scal[B_NEV] = 0; scal[B_NCAND] = 0; }
         const int nsucc_tot = scal[B_NSUCC];
         // classify the events against the lowest DEFINITE caller of every bucket
         for (int k = tid; k < N; k += TB) {
-            const int2 ev = gev[k];
+            const int2 ev = ev_get(k);
             const int type = ev.y & 7, p = (ev.y >> 4) & 0xff;
             if (type == EVB_RESETCAND) {
                 // a call on its old bucket by a definite caller with a lower index bumps it: cannot re-join (99.7 % of them)
-                if (fcallA[(ev.y >> 12) & 0xff] < ev.x) gev[k].y = 0;
+                if (fcallA[(ev.y >> 12) & 0xff] < ev.x) ev_kill(k);
                 else { const int s = atomicAdd(&scal[B_NRC], 1); if (s < RCCAP) BI(bl::RCL)[s] = k; }
             } else if (type == EVB_RJOIN) {
                 atomicAdd(&scal[B_NRJ], 1);
@@ -457,15 +462,15 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         // ---- resolve ----
         const int nrc = scal[B_NRC];
         if (nrc > 0) { // rare: reset cycles that may re-join — decided strictly in index order by one wavefront, then recount
-            if (nrc > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (nrc > RCCAP) { status = PRACH_ERR_INTERNAL; why = 2; time_exit = t; break; }
             if (tid < 64) { // (first-caller table in registers, lane = bucket: prach_cluster.hip resolve_reset_candidates)
                 const int n = __builtin_amdgcn_readfirstlane(nrc);
                 int *const rcl = BI(bl::RCL), *const sidx = BI(bl::SIDX);
                 int f0 = lane < nP ? fcallA[lane] : INT_MAX;
                 for (int c = lane; c < n; c += 64) { // rank-sort the candidates by UE index into SIDX (free at this point)
-                    const int myidx = gev[rcl[c]].x;
+                    const int myidx = ev_get(rcl[c]).x;
                     int rank = 0;
-                    for (int j = 0; j < n; j++) rank += gev[rcl[j]].x < myidx ? 1 : 0;
+                    for (int j = 0; j < n; j++) rank += ev_get(rcl[j]).x < myidx ? 1 : 0;
                     sidx[rank] = rcl[c];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 for (int base = 0; base < n; base += 64) {
                     const int mm = min(64, n - base);
                     int es = 0, cidx = 0, cinfo = 0;
-                    if (lane < mm) { es = sidx[base + lane]; const int2 e = gev[es]; cidx = e.x; cinfo = e.y; }
+                    if (lane < mm) { es = sidx[base + lane]; const int2 e = ev_get(es); cidx = e.x; cinfo = e.y; }
                     int cancelled = 0;
                     for (int s_ = 0; s_ < mm; s_++) {
                         const int idx = __builtin_amdgcn_readlane(cidx, s_), info = __builtin_amdgcn_readlane(cinfo, s_);
@@ -482,13 +487,13 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                         if (__builtin_amdgcn_readlane(f0, q & 63) < idx) { if (lane == s_) cancelled = 1; } // bumped before its turn
                         else if (idx < __builtin_amdgcn_readlane(f0, p & 63)) { if (lane == (p & 63)) f0 = idx; } // its call becomes the first on p
                     }
-                    if (lane < mm && cancelled) gev[es].y = 0;
+                    if (lane < mm && cancelled) ev_kill(es);
                 }
                 if (lane < nP) fcallA[lane] = f0;
             } else if (tid < 64 + NPB) { BI(bl::NLV)[tid - 64] = 0; BI(bl::FIE)[tid - 64] = 0; }
             __syncthreads();
             for (int k = tid; k < N; k += TB) {
-                const int2 e = gev[k];
+                const int2 e = ev_get(k);
                 const int type = e.y & 7, p = (e.y >> 4) & 0xff;
                 if (type == EVB_LEAVER) { if (e.x < fcallA[p]) atomicAdd(&BI(bl::NLV)[p], 1); }
                 else if ((type == EVB_CALLER || type == EVB_RESETCAND) && e.x == fcallA[p]) BI(bl::FIE)[p] = 1;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 int idx = 0, p = 0, ispre = 0;
                 bool caller = false;
                 if (k < N) {
-                    const int2 e = gev[k];
+                    const int2 e = ev_get(k);
                     const int type = e.y & 7;
                     if (type == EVB_CALLER || type == EVB_RESETCAND) { caller = true; idx = e.x; p = (e.y >> 4) & 0xff; ispre = (e.y >> 3) & 1; }
                 } else {
@@ -516,12 +521,12 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 if (nrj > 0) { // Msg3-timeout re-entries that stayed matched since the previous call on this bucket (rare)
                     int prev = (!first) ? fcallA[p] : -1;
                     for (int j = 0; j < N; j++) {
-                        const int2 ej = gev[j];
+                        const int2 ej = ev_get(j);
                         const int tj = ej.y & 7;
                         if ((tj == EVB_CALLER || tj == EVB_RESETCAND) && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) prev = ej.x;
                     }
                     for (int j = 0; j < N; j++) {
-                        const int2 ej = gev[j];
+                        const int2 ej = ev_get(j);
                         if ((ej.y & 7) == EVB_RJOIN && ((ej.y >> 4) & 0xff) == p && ej.x < idx && ej.x > prev) rj++;
                     }
                 }
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         __syncthreads(); // S5: calls done; singles listed
         BSTAMP(10);
         const int ns = scal[B_NS];
-        if (ns > BSC) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+        if (ns > BSC) { status = PRACH_ERR_INTERNAL; why = 3; time_exit = t; break; }
         const int Gr = max(0, nGrantUL - 1 - grantCheck); // Beta.c:336-347
         auto grant = [&](const int my) { __hip_atomic_fetch_or(pw + my, PW_GRANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // ONE fire-and-forget L2 atomic
         if (Gr > 0 && ns > 0 && ns <= 64) {
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             }
             __syncthreads();
             const int ncross = scal[B_NCROSS];
-            if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; time_exit = t; break; }
+            if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; why = 4; time_exit = t; break; }
             if (tid < ncross) {
                 const int my = rcl[tid];
                 int rank = bins[my >> binshift];
@@ -657,6 +662,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         o->ptcSum = scal[B_PTC]; o->fcSum = scal[B_FC];
         o->nSuccess = scal[B_NSUCC]; o->finalSuccess = scal[B_NSUCC]; o->continueFailed = scal[B_CONTF];
         o->status = status;
+        o->hard_error = why; // (1 events, 2 reset-cycle candidates, 3 singleton callers, 4 crossing bin: reported by the engine)
         o->time_exit = time_exit;
         o->collisionPreambles = scal[B_COLL]; o->totalPreambleTxop = scal[B_TXOP];
         o->activeCheck = activeCheck;

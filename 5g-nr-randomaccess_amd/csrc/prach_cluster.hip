@@ -1317,6 +1317,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void cluster_kernel(const TrialDev *
         gadd(&o->finalSuccess, L.scal[C_NSUCC]);
         gadd(&o->continueFailed, L.scal[C_CONTF]);
         if (status != PRACH_OK) gmin(&o->status, status);
+        if (status == PRACH_ERR_INTERNAL) o->hard_error = 1; // (a capacity was exceeded: that, not a peer's time-out, is what the engine must act on)
         if (b == 0) {
 #ifdef PRACH_STAMPS
             for (int k = 0; k < 8; k++) o->stamps6[k] = stamps[k];

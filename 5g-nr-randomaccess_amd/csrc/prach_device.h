@@ -46,8 +46,9 @@ struct DevResult {
     unsigned long long dbg[4];
     unsigned long long stamps6[8]; // diagnostic build: cycles per phase (pass, publish, barrier, gather, resolve, grants)
     unsigned long long fstamps[24]; // diagnostic build: finer split (prach_cluster.hip FSTAMP)
-    unsigned long long visits, events; // cluster_kernel: 64-UE group visits of the compacted pass's phase A, UEs through its phase B (the
-                                       // kernel's OWN memory work: a visit reads one hot record per lane, an event reads and writes a UE)
+    unsigned long long visits, events; // one workgroup per trial: 64-UE group visits of the pass, UEs through the event body (the kernel's OWN memory work)
+    int hard_error;                    // a workgroup of the trial left with PRACH_ERR_INTERNAL (a per-subframe capacity): wins over a peer's PRACH_ERR_TIMEOUT in `status`
+    int pad_;
 };
 
 struct TrialDev {
@@ -81,6 +82,7 @@ struct TrialDev {
     int4 *rec32;                 // [nUE][2] the 32-byte event record
     unsigned *pw;                // [whole 64-UE groups] pass words
     int *qov;                    // [nUE] event queue of a subframe beyond its LDS part
+    int2 *evov;                  // [2 nUE] the resolver's event list of a subframe beyond its LDS part
 };
 
 constexpr int WG_THREADS = 1024;

@@ -64,7 +64,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, cand;
     size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0, sector;
-    size_t rec32, pw, qov; // batch kernel
+    size_t rec32, pw, qov, evov; // batch kernel
     size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
     int evw, mbstride;
@@ -120,9 +120,9 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         const prach_cfg &c = cfgs[idx[k]];
         TrialLayout &T = L.t[k];
         const size_t n = (size_t)c.nUE;
-        T.rec = T.ptc = T.ftt = T.stt = T.fcnt = T.nd = T.rec32 = T.pw = T.qov = 0;
+        T.rec = T.ptc = T.ftt = T.stt = T.fcnt = T.nd = T.rec32 = T.pw = T.qov = T.evov = 0;
         if (batch) { // prach_batch.hip: 32-byte event records, pass words padded to whole 64-UE groups, the queue's global part
-            T.rec32 = take(32 * n); T.pw = take(4 * ((n + 63) / 64 * 64 + 64)); T.qov = take(4 * n);
+            T.rec32 = take(32 * n); T.pw = take(4 * ((n + 63) / 64 * 64 + 64)); T.qov = take(4 * n); T.evov = take(16 * n);
         } else {
             T.rec = take(16 * n);
             T.ptc = take(4 * n); T.ftt = take(4 * n); T.stt = take(4 * n); T.fcnt = take(4 * n); T.nd = take(4 * n);
@@ -275,7 +275,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.dense_pass = e->opt_dense ? 1 : 0;
         d.pipeline = e->opt_pipeline ? 1 : 0;
         if (batch) {
-            d.rec32 = reinterpret_cast<int4 *>(A + L.rec32); d.pw = reinterpret_cast<unsigned *>(A + L.pw); d.qov = reinterpret_cast<int *>(A + L.qov);
+            d.rec32 = reinterpret_cast<int4 *>(A + L.rec32); d.pw = reinterpret_cast<unsigned *>(A + L.pw); d.qov = reinterpret_cast<int *>(A + L.qov); d.evov = reinterpret_cast<int2 *>(A + L.evov);
         } else {
             d.rec = reinterpret_cast<int4 *>(A + L.rec);
             d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);
@@ -439,7 +439,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         const DevResult &dr = drs[k];
         prach_result &r = results[idx[k]];
         std::memset(&r, 0, sizeof(r));
-        r.status = dr.status;
+        r.status = (dr.hard_error && dr.status == PRACH_ERR_TIMEOUT) ? PRACH_ERR_INTERNAL : dr.status; // (a capacity overflow somewhere in the cluster is the cause, a peer's time-out its effect)
         r.time_exit = dr.time_exit;
         r.maxTime = prach_max_time(&c);
         r.nSuccessUE = dr.nSuccess;
@@ -476,6 +476,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             for (int q = 0; q < 20; q++) if (names[q][0] != '-') std::fprintf(stderr, " %s=%.0f", names[q], dr.fstamps[q] / (double)dr.steps);
             std::fprintf(stderr, "\n");
         }
+        if (dr.status == PRACH_ERR_INTERNAL && e->last.rec_mode == CLUSTER_REC_BATCH && std::getenv("PRACH_VERBOSE"))
+            std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d left at subframe %d: capacity %d (1 events, 2 reset-cycle candidates, 3 singleton callers, 4 crossing bin)\n", c.nUE, dr.time_exit, dr.hard_error);
         if (dr.status != PRACH_OK) continue;
         // totalDelay is a FLOAT running sum in index order (Beta.c:186,193): exact in integer
         // arithmetic while it stays below 2^24, otherwise replay the float additions on the host.
@@ -577,14 +579,22 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             auto work = [&](int k) { return (uint64_t)cfgs[k].nUE * (uint64_t)(cfgs[k].max_steps > 0 ? cfgs[k].max_steps : prach_max_time(&cfgs[k])); };
             return work(a) > work(b);
         });
-        bool cluster_ok = !e->opt_legacy;
-        int maxP = 1;
-        for (int k : idx) {
-            cluster_ok = cluster_ok && cfgs[k].nUE < (1 << 20) - 1; // 20-bit granule fields, dead-group bitmap
-            cluster_ok = cluster_ok && !(cfgs[k].flags & PRACH_FLAG_SECTOR_GRANTS); // the dormant per-sector grant path runs on trial_kernel (index-ordered, exact)
-            if (mode == PRACH_RNG_GLIBC) cluster_ok = cluster_ok && cfgs[k].nUE <= CLUSTER_GLIBC_MAX_UE;
-            maxP = std::max(maxP, cfgs[k].nPreamble);
+        // trials only trial_kernel runs (index-ordered, exact, one workgroup each): the dormant per-sector grant path, sizes beyond the
+        // cluster kernels' 20-bit granule fields / group tables — they leave the others on the cluster kernels
+        std::vector<int> solo;
+        {
+            std::vector<int> rest;
+            for (int k : idx) {
+                const bool only_trial_kernel = (cfgs[k].flags & PRACH_FLAG_SECTOR_GRANTS) || cfgs[k].nUE >= (1 << 20) - 1 ||
+                                               (mode == PRACH_RNG_GLIBC && cfgs[k].nUE > CLUSTER_GLIBC_MAX_UE);
+                (only_trial_kernel ? solo : rest).push_back(k);
+            }
+            idx.swap(rest);
         }
+        const bool cluster_ok = !e->opt_legacy && !idx.empty();
+        int maxP = 1;
+        for (int k : idx) maxP = std::max(maxP, cfgs[k].nPreamble);
+        if (!cluster_ok) { idx.insert(idx.end(), solo.begin(), solo.end()); solo.clear(); }
         if (cluster_ok) {
             // production path: cluster kernel, G workgroups per trial.  The workgroups of a cluster wait for each other, so
             // every cluster of the launch must be resident: G x trials <= what the occupancy query admits for this kernel
@@ -633,8 +643,23 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             }
             e->pack_off = false;
             idx.swap(fallback);
+            if (!idx.empty()) note_fallback(e, (G > 1 && mode == PRACH_RNG_PHILOX && e->opt_batch) ? "prach::batch_kernel (one workgroup per trial, event queue without a capacity)"
+                                                                                                    : "trial_kernel (one workgroup per trial, no per-subframe capacity)", idx.size(), nto, G);
+            if (!idx.empty() && G > 1 && mode == PRACH_RNG_PHILOX && e->opt_batch) {
+                // Overflow without the cliff: most capacities a cluster trips over are PER WORKGROUP (512 event granules per mailbox, the
+                // candidate list) or come with its LDS-resident layout; prach::batch_kernel has neither (one workgroup, the event queue
+                // continues in global memory) and still runs all 16 wavefronts on the trial, so such trials go there first — the
+                // one-workgroup, index-ordered trial_kernel (no per-subframe capacity at all, ~10x slower) only gets what is left.
+                int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, 1, kernel_ms, upload_ms);
+                if (rc != PRACH_OK) return rc;
+                std::vector<int> still;
+                for (int k : idx) if (results[k].status != PRACH_OK) still.push_back(k);
+                idx.swap(still);
+                if (!idx.empty()) std::fprintf(stderr, "[prach] %zu of them exceeded a capacity of the batch kernel's resolver too: rerun on trial_kernel\n", idx.size());
+            }
+            e->last.trial_kernel_reruns += (int32_t)idx.size();
+            idx.insert(idx.end(), solo.begin(), solo.end());
             if (idx.empty()) continue;
-            note_fallback(e, "trial_kernel (one workgroup per trial, no per-subframe capacity)", idx.size(), nto, G);
         }
         int attempt = 0;
         while (!idx.empty()) {

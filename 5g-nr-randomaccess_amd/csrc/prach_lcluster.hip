@@ -55,7 +55,11 @@ constexpr int NPCL = 64;     // stride of the per-bucket tables (nPreamble <= 64
 constexpr int NWA = NW - 1;
 constexpr int LEV = 4096;    // gathered events per subframe
 constexpr int LSC = 2048;    // singleton callers per subframe
+#ifdef PRACH_QCAP
+constexpr int LCC = 8;       // (test build: the candidate list overflows in ordinary trials, so that the path below is exercised)
+#else
 constexpr int LCC = 1024;    // early-leaver candidates per workgroup and subframe
+#endif
 constexpr int LQ = CLUSTER_LQCAP; // event queue = at most every owned UE slot
 constexpr int LGB = 1024;    // grant selection bins
 constexpr int LEPF = 32;     // event granules of every mailbox fetched together with the bucket granules (more: a second round)
@@ -626,7 +630,9 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             }
             // publish: header {#events, overflow, #successes} (the pair of counters is reset behind S3 — every thread has read it by
             // then — and used again by the pass of subframe t + 2, two unconditional barriers later)
-            if (tl == 64) lstx(sx, mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | (nevraw > CLUSTER_EVW ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
+            // (the overflow bit also carries a capacity this workgroup ALONE has exceeded in its pass — the candidate list — so that every
+            //  workgroup of the cluster leaves at the same S3 with PRACH_ERR_INTERNAL instead of spinning for a peer that has left)
+            if (tl == 64) lstx(sx, mygr, lmk((unsigned)min(nevraw, CLUSTER_EVW) | ((nevraw > CLUSTER_EVW || scal[S_STATUS] == PRACH_ERR_INTERNAL) ? (1u << 13) : 0u), (unsigned)scal[S_NSUCC], tag));
         }
         LSTAMP(5); // publish
         // Phase A of the NEXT subframe runs while the other workgroups' granules are on their way; then round 1 is issued — the bucket
@@ -923,6 +929,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         gadd(&o->finalSuccess, scal[S_NSUCC]);
         gadd(&o->continueFailed, scal[S_CONTF]);
         if (status != PRACH_OK) gmin(&o->status, status);
+        if (status == PRACH_ERR_INTERNAL) o->hard_error = 1; // (a capacity was exceeded: that, not a peer's time-out, is what the engine must act on)
         if (b == 0) {
 #ifdef PRACH_STAMPS
             for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];

@@ -42,7 +42,17 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_UPDATE = 32.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 KERNEL_NAMES = {0: "prach::cluster_kernel (records in global memory)", 1: "prach::cluster_kernel (8+4 B records, one workgroup per trial)",
-                2: "prach::cluster_kernel (LDS-resident records)", 3: "prach::lcluster_kernel (LDS-resident UE state)"}
+                2: "prach::cluster_kernel (LDS-resident records)", 3: "prach::lcluster_kernel (LDS-resident UE state)",
+                4: "prach::batch_kernel (one workgroup per trial: 4-byte pass words + 32-byte event records)"}
+
+
+def own_bytes(tm):
+    """The bytes the one-workgroup-per-trial kernel itself asks for, from its own counters (prach_timing.group_visits / .event_ues).
+    batch_kernel: a 64-UE group visit reads one 4-byte pass word per lane; an event UE reads and writes one 32-byte record, writes its
+    pass word and passes through the event queue (4 B in, 4 B out): 76 B.  The general kernel's 8 + 4 byte form: 8 B per lane and
+    visit, ~40 B per event."""
+    vis, ev = (256, 76) if tm.rec_mode == 4 else (512, 40)
+    return tm.group_visits * vis + tm.event_ues * ev
 
 
 def cpu_reference_baseline(budget_s: float):
@@ -235,7 +245,7 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
             res.extend(r)
             tmc = eng.timing()
             kms += tmc.kernel_ms
-            own += tmc.group_visits * 64 * 8 + tmc.event_ues * 40  # the kernel's OWN bytes: 8 B per visited UE + 40 B per event UE
+            own += own_bytes(tmc)
         t_sim = time.perf_counter() - t0
         agg = distmod.aggregate_rows(my_cfgs, res, points)  # raises if a trial did not return PRACH_OK
         tot = distmod.allreduce_aggregates(agg, device=cdev if (dist is not None and args.backend == "nccl") else None)
@@ -285,17 +295,17 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
         "per_rank_sim_seconds": per_rank, "imbalance": (max(per_rank) / mean_rank - 1.0) if mean_rank > 0 else 0.0,
         "rank0_step_seconds": {"simulation": sum(sims) / args.steps, "whole_step_incl_allreduce_and_gather": sum(steps_t) / args.steps},
         # rank 0's kernels.  In this regime (one workgroup per trial, thousands in flight) the kernel skips finished / not yet arrived 64-UE
-        # groups, reads 8 B per visited UE and does not rewrite a UE in steady contention, so the 32 B per update of the reference's dense
-        # formulation is not what it moves: the fraction is built from the kernel's OWN bytes (counted by the kernel: group visits x 64 x 8 B
-        # + event UEs x 40 B) and the dense-formulation rate is carried beside it, labelled.
+        # groups, reads ONE 4-byte pass word per visited UE and touches a UE's 32-byte record only on its events, so the 32 B per update of
+        # the reference's dense formulation is not what it moves: the fraction is built from the kernel's OWN bytes (counted by the kernel:
+        # own_bytes()) and the dense-formulation rate is carried beside it, labelled.
         "roofline": {"bound": "hbm", "achieved": sum(owns) / (sum(kmss) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": sum(owns) / (sum(kmss) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "prach::cluster_kernel (8+4 B records, one workgroup per trial)", "kernel_ms_rank0": sum(kmss) / args.steps,
-                     "bytes": "the kernel's own bytes: 8 B per visited UE + 40 B per event UE (prach_timing.group_visits / .event_ues), rank 0",
+                     "traffic": None, "kernel": "prach::batch_kernel (4-byte pass words + 32-byte event records, one workgroup per trial)", "kernel_ms_rank0": sum(kmss) / args.steps,
+                     "bytes": "the kernel's own bytes: 256 B per 64-UE group visit + 76 B per event UE (prach_timing.group_visits / .event_ues), rank 0",
                      "own_bytes_per_update": sum(owns) / max(1, updates_per_step * args.steps / world),
                      "dense_formulation_GBps_32B_per_update": ALGO_BYTES_PER_UPDATE * updates_per_step / world / (sum(kmss) / args.steps * 1e-3) / 1e9,
-                     "note": "counter-measured HBM traffic of this regime (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes): profiles/r02_summary.md "
-                             "(config 3: 3.58 TB/s = 45 % of peak, 1.9x the own bytes: the event body's scattered 4- and 8-byte accesses move whole sectors)"},
+                     "note": "counter-measured HBM traffic of this regime (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes): profiles/r03_config3.md "
+                             "(config 3: 6.3 B per update counted against 4.3 own: an event fetches a whole 128-byte line for its 32-byte record)"},
         # The N = 1 line of the driver's scaling run is the single-trial workload (configs[1]), a DIFFERENT workload: the one-GPU figure of this
         # grid regime travels in that same N = 1 line as extras.grid_one_gpu (measured in that run, --times 100), and every N > 1 line carries
         # value_per_gpu, so that a scaling efficiency can be formed from measured records only (no constant is pasted in here).
@@ -400,18 +410,17 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
         upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
         tm3 = eng.timing()
         kms = tm3.kernel_ms
-        # the kernel's OWN bytes: a group visit of phase A reads one 8-byte hot record per lane; a UE through the event body reads 8 + 4 + 4 B
-        # (record, timer base, draw index) and writes about as much, plus ~8 B of cold fields
-        own = tm3.group_visits * 64 * 8 + tm3.event_ues * 40
+        own = own_bytes(tm3)  # the kernel's OWN bytes
         extras["config3_sweep_x100_1000_trials"] = {
             "kernel_updates_per_s": upd / (kms * 1e-3), "kernel_ms": kms, "updates": upd,
             "algorithmic_GBps_32B_per_update": 32.0 * upd / (kms * 1e-3) / 1e9,
             "own_traffic": {"group_visits": tm3.group_visits, "event_ues": tm3.event_ues, "own_bytes": own, "own_bytes_per_update": own / upd,
                             "own_GBps": own / (kms * 1e-3) / 1e9, "frac_of_hbm_peak": own / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "counter_traffic": "profiles/: FETCH_SIZE x2 + WRITE_SIZE of the same launch (compare: bytes beyond own_bytes are waste)"},
+            "kernel": KERNEL_NAMES.get(tm3.rec_mode, "?"),
             "note": "32 B per update are the algorithmic bytes of the reference's dense formulation; the kernel skips finished / not yet arrived groups, "
-                    "reads 8 B per visited UE and does not rewrite a UE in steady contention, so this is NOT an HBM fraction: the counter traffic of "
-                    "this launch (FETCH_SIZE / WRITE_SIZE, separate passes) is in profiles/",
+                    "reads 4 B per visited UE and touches a UE's 32-byte record only on its events, so this is NOT an HBM fraction: the counter traffic of "
+                    "this launch (FETCH_SIZE / WRITE_SIZE, separate passes) is in profiles/r03_config3.md",
             "mean_success_ratio_100k": sum(r_.nSuccessUE for c, r_ in zip(cfgs, rs) if c.nUE == 100000) / 100 / 1e5}
         # (3b) the sharded grid's regime on ONE GPU (the denominator of the N > 1 lines' scaling): the Beta.c program's sweep x --times 100,
         #      1000 trials in one call
@@ -421,7 +430,7 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
         wall = time.perf_counter() - t1
         upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
         tmg = eng.timing()
-        extras["grid_one_gpu"] = {"workload": "configs[4]'s grid with --times 100: 1000 Beta.c trials (nUE 10k..100k), one call, one launch",
+        extras["grid_one_gpu"] = {"workload": "configs[4]'s grid with --times 100: 1000 Beta.c trials (nUE 10k..100k), one call, one launch", "kernel": KERNEL_NAMES.get(tmg.rec_mode, "?"),
                                   "kernel_updates_per_s": upd / (tmg.kernel_ms * 1e-3), "wall_updates_per_s": upd / wall, "kernel_ms": tmg.kernel_ms,
                                   "updates": upd, "trials": len(cfgs), "bad": sum(r_.status != 0 for r_ in rs), "fallback_trials": tmg.fallback_trials}
         # (4) BASELINE config 4: NOMA.c power-level grouping, nUE=100 000, one trial (activation tables built on all host cores: inclusive rate too)

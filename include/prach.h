@@ -110,7 +110,9 @@ typedef struct prach_timing {
     int32_t resident_limit;  /* workgroups the runtime's occupancy query admits at once for the cluster kernel and its LDS
                                 size; a cluster launch never exceeds it (its workgroups wait for each other) */
     int32_t fallback_trials; /* trials of the last call that a cluster launch could not finish and that were rerun (exactly) on
-                                a kernel that waits for nobody: a per-subframe capacity exceeded, or a peer wait timed out */
+                                a kernel that waits for nobody: a per-subframe capacity exceeded, or a peer wait timed out.  Philox
+                                trials go to prach::batch_kernel first (one workgroup per trial, event queue without a capacity);
+                                trial_kernel_reruns (below) counts the ones that ended on the slow index-ordered trial_kernel */
     int32_t spin_timeouts;   /* ... of which: peer waits that timed out (PRACH_ERR_TIMEOUT) */
     int32_t rec_mode;        /* which kernel / record form the last cluster launch used: 0 prach::cluster_kernel, 16-byte records in global
                                 memory; 1 the same with 8 + 4 byte records (one workgroup per trial: the glibc modes); 2 the same with
@@ -122,6 +124,8 @@ typedef struct prach_timing {
     uint64_t event_ues;      /* ... and UEs that went through the full event body: the kernel's OWN memory work, for a roofline built from
                                 the bytes it really moves (batch_kernel: a visit reads one 4-byte pass word per lane, an event reads and
                                 writes one 32-byte record and one pass word) */
+    int32_t trial_kernel_reruns; /* of fallback_trials: trials that were (also) rerun on the one-workgroup, index-ordered trial_kernel */
+    int32_t reserved_;
 } prach_timing;
 
 typedef struct prach_engine prach_engine;

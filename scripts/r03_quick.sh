@@ -1,9 +1,6 @@
 set -e
-for X in "" x4; do
-for W in 8 16; do
-echo "variant=$X waves=$W"
-if [ -n "$X" ]; then export PRACH_LIB=$GRAFT_REPO_ROOT/5g-nr-randomaccess_amd/libprach_hip_$X.so; fi
-PRACH_ENG_OPTS=batch_waves=$W python3 scripts/gpu_batch.py 100 1 0 2>&1 | head -1
-PRACH_ENG_OPTS=batch_waves=$W python3 scripts/gpu_batch.py 100 0 0 2>&1 | head -1
-done
-done
+python -m pytest tests -m gpu -x -q -k "fallback or overflow or sector or lean_cluster or residency or two_engines" 2>&1 | tail -4
+python3 tests/tools/gpu_fuzz_lean.py 31 300 2>&1 | grep -v "^\[prach\]" | tail -2
+python3 tests/tools/gpu_fuzz_lean.py 32 30 big 2>&1 | grep -v "^\[prach\]" | tail -2
+python3 tests/tools/gpu_fuzz_batch.py 33 80 2>&1 | grep -v "^\[prach\]" | tail -2
+python3 tests/tools/gpu_fuzz.py 34 200 2>&1 | grep -v "^\[prach\]" | tail -2

@@ -313,7 +313,8 @@ def test_cluster_capacity_fallback_is_exact(pkg, ob, engine):
     kw = dict(nPreamble=3, backoff=1, nGrantUL=12, maxRarWindow=2, maxMsg2TxCount=3)
     cfg = pkg.make_cfg(60000, variant=1, rng_mode=pkg.RNG_PHILOX, seed=2, **kw)
     (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
-    assert engine.timing().launches == 2  # cluster attempt + exact rerun
+    tm = engine.timing()
+    assert tm.launches >= 2 and tm.fallback_trials == 1  # cluster attempt + exact rerun (on the batch kernel first, on trial_kernel if that overflows too)
     ores, oues = ob.run_trial(ob.make_cfg(60000, variant=1, **kw), ob.Rng(ob.RNG_PHILOX, 2))
     assert_same(pkg, res, logs, ores, oues, "fallback")
 
@@ -831,3 +832,37 @@ def test_event_queue_overflow_is_exact(pkg):
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "done 250 cases 0 bad" in out.stdout, out.stdout[-2000:]
+
+
+def test_lean_cluster_local_overflow_leaves_together(ob):
+    """A capacity that ONE workgroup of a lean cluster exceeds in its own pass (the early-leaver candidate list) is published to the
+    whole cluster through the header granule's overflow bit: every workgroup leaves at the same subframe with PRACH_ERR_INTERNAL and
+    the engine reruns the trial exactly, at once — no peer spins into a time-out, nothing is reported as "not co-resident".
+    libprach_hip_tinyq.so is built with an 8-entry candidate list, so an ordinary overloaded trial gets there."""
+    import ctypes as C2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, os, time
+sys.path.insert(0, %r)
+import numpy as np
+import __graft_entry__ as g
+from oracle import binding as ob
+m = g.load_package()
+eng = m.Engine(0)
+eng.set("lds_records", 1); eng.set("cluster", 8)
+cfg = m.make_cfg(20000, variant=1, rng_mode=m.RNG_PHILOX, seed=4)
+t0 = time.time()
+(res,), (logs,) = eng.run_trials([cfg], want_logs=True)
+wall = time.time() - t0
+tm = eng.timing()
+ores, oues = ob.run_trial(ob.make_cfg(20000, variant=1), ob.Rng(ob.RNG_PHILOX, 4))
+a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16); b = np.frombuffer(oues, dtype=np.int32).reshape(-1, 16)
+print("RESULT", res.status, tm.fallback_trials, tm.spin_timeouts, int((a != b).any()), res.nSuccessUE == ores.nSuccessUE, round(wall, 2))
+""" % root
+    lib = os.path.join(root, "5g-nr-randomaccess_amd", "libprach_hip_tinyq.so")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PRACH_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.split("\n") if l.startswith("RESULT")][0].split()
+    status, fallback, timeouts, differs, same_succ, wall = int(line[1]), int(line[2]), int(line[3]), int(line[4]), line[5], float(line[6])
+    assert (status, fallback, timeouts, differs, same_succ) == (0, 1, 0, 0, "True"), out.stdout + out.stderr[-1500:]
+    assert wall < 5.0, f"the overflowing cluster took {wall} s: its workgroups waited for each other"

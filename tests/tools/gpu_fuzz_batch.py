@@ -18,7 +18,7 @@ eng.set("cluster", 1)
 seed, ncalls = int(sys.argv[1]), int(sys.argv[2])
 big = len(sys.argv) > 3
 rs = np.random.RandomState(seed)
-bad = ntr = notbatch = 0
+bad = ntr = notbatch = tkr = 0
 t0 = time.time()
 sizes = [1, 5, 63, 64, 65, 100, 300, 1000, 2000, 3500, 5000, 8000, 12000] + ([20000, 30000, 50000, 70000] if big else [])
 for k in range(ncalls):
@@ -47,6 +47,7 @@ for k in range(ncalls):
         continue
     tm = eng.timing()
     notbatch += tm.rec_mode != 4 or tm.fallback_trials != 0
+    tkr += tm.trial_kernel_reruns
 
     def one(j):
         v, nUE, kw, s = descs[j]
@@ -62,4 +63,4 @@ for k in range(ncalls):
             print("call", k, "trial", j, descs[j], "MISMATCH", str(e)[:400], flush=True)
     if k % 20 == 19:
         print(f"... {k + 1} calls, {ntr} trials, {bad} bad, {notbatch} calls not (only) on the batch kernel, {time.time() - t0:.0f} s", flush=True)
-print("done", ncalls, "calls", ntr, "trials", bad, "bad", notbatch, "calls not (only) on the batch kernel")
+print("done", ncalls, "calls", ntr, "trials", bad, "bad", notbatch, "calls not (only) on the batch kernel;", tkr, f"trials rerun on trial_kernel = {100.0 * tkr / max(ntr, 1):.1f} %")

@@ -17,7 +17,7 @@ eng = pkg.Engine(0)
 seed, ncase = int(sys.argv[1]), int(sys.argv[2])
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rs = np.random.RandomState(seed)
-bad = lean = fb = 0
+bad = lean = fb = tkr = 0
 t0 = time.time()
 for k in range(ncase):
     if big:
@@ -47,6 +47,7 @@ for k in range(ncase):
     tm = eng.timing()
     lean += tm.rec_mode == 3 and tm.fallback_trials == 0
     fb += tm.fallback_trials
+    tkr += tm.trial_kernel_reruns
     ores, oues = ob.run_trial(ob.make_cfg(nUE, variant=v, **kw), ob.Rng(1, s))
     try:
         tgp.assert_same(pkg, res, logs, ores, oues, k)
@@ -55,4 +56,4 @@ for k in range(ncase):
         print("case", k, desc, "MISMATCH", str(e)[:400], flush=True)
     if k % 50 == 49:
         print(f"... {k + 1} cases, {bad} bad, {lean} on the lean kernel, {fb} fallbacks, {time.time() - t0:.0f} s", flush=True)
-print("done", ncase, "cases", bad, "bad;", lean, "ran on the lean kernel,", fb, "fell back")
+print("done", ncase, "cases", bad, "bad;", lean, "ran on the lean kernel,", fb, "fell back (to the batch kernel),", tkr, f"of them on to trial_kernel = {100.0 * tkr / ncase:.1f} % of the cases")
