@@ -437,9 +437,32 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
         cfg = pkg.make_cfg(args.nue, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=0)
         (r,), _ = eng.run_trials([cfg])
         tmn = eng.timing()
+        def noma_roofline(upd, ue_slots, kms, tm_):
+            # prach::noma_kernel loads and stores a UE's 16-byte record ONCE per 5 ms access slot (NOMA.c:665-711 runs the grouping per slot
+            # and the four subframes behind it on registers), so its own bytes are per UE-SLOT, not per update: 16 B in + 16 B out.
+            own = 32.0 * ue_slots
+            return {"bound": "hbm", "achieved": ALGO_BYTES_PER_UPDATE * upd / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ALGO_BYTES_PER_UPDATE * upd / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": f"prach::noma_kernel, {tm_.cluster_size} workgroup(s) per trial", "kernel_ms": kms,
+                    "own_bytes": own, "own_GBps": own / (kms * 1e-3) / 1e9, "own_bytes_per_update": own / upd,
+                    "note": "achieved = ALGORITHMIC 32 B per UE-subframe update / kernel time; own = 32 B per UE and access slot (the record is loaded and "
+                            "stored once per 5 ms); counter-measured HBM traffic of both launches: profiles/r03_noma.md (the state of a trial stays in L2: "
+                            "50 MB of HBM traffic per 100 000-UE trial) — the kernel is bound by one cross-CU exchange + the per-sector resolve per slot"}
+        slots = args.nue * ((r.steps + 4) // 5)
         extras["noma_c_single_trial"] = {"kernel_updates_per_s": args.nue * r.steps / (tmn.kernel_ms * 1e-3),
                                          "inclusive_updates_per_s_with_host_activation_tables": args.nue * r.steps / (tmn.total_ms * 1e-3),
-                                         "nSuccessUE": r.nSuccessUE, "upload_ms_activation_table": tmn.upload_ms}
+                                         "nSuccessUE": r.nSuccessUE, "upload_ms_activation_table": tmn.upload_ms,
+                                         "roofline": noma_roofline(args.nue * r.steps, slots, tmn.kernel_ms, tmn)}
+        # (4b) NOMA.c's OWN experiment (NOMA.c:637-719: 10 seeds x the ten sweep points), all 100 trials in one call
+        cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(10) for n in range(10000, 100001, 10000)]
+        t1 = time.perf_counter()
+        rs, _ = eng.run_trials(cfgs)
+        wall = time.perf_counter() - t1
+        tmb = eng.timing()
+        upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
+        slots = sum(c.nUE * ((r_.steps + 4) // 5) for c, r_ in zip(cfgs, rs))
+        extras["noma_c_experiment_batched"] = {"trials": len(cfgs), "kernel_updates_per_s": upd / (tmb.kernel_ms * 1e-3), "wall_updates_per_s_with_host_activation_tables": upd / wall,
+                                               "updates": upd, "bad": sum(r_.status != 0 for r_ in rs), "roofline": noma_roofline(upd, slots, tmb.kernel_ms, tmb)}
         out["extras"] = extras
     if world == 1 and not args.no_cpu:
         from oracle import binding as ob
