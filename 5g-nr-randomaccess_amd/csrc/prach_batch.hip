@@ -59,13 +59,6 @@ template <int NWB> struct BCap {
     static constexpr int LCAP = BGROUPS / NWB;            // live 64-UE groups per wavefront
 };
 
-constexpr unsigned PW_IDLE = 0x0000FFFFu;  // not arrived yet
-constexpr unsigned PW_DONE = 0x4000FFFFu;  // finished for good
-constexpr unsigned PW_GRANT = 0x80000000u;
-__device__ __forceinline__ unsigned pw_make(const int tj, const int dur, const int pre) {
-    return ((unsigned)tj & 0xFFFFu) | ((unsigned)dur << 16) | ((unsigned)pre << 24);
-}
-
 constexpr int EVB_CALLER = UEV_CALLER, EVB_RESETCAND = UEV_RESETCAND, EVB_RJOIN = UEV_RJOIN, EVB_LEAVER = 4;
 
 enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_SPARE, B_NEV, B_NCAND, B_QN, B_NCROSS, B_PTC, B_FC, B_SUMT = 16, B_ND = 18,
@@ -122,40 +115,6 @@ __device__ __forceinline__ ColdRegs cold_unpack(const int4 b) {
 }
 __device__ __forceinline__ int4 cold_pack(const unsigned nd, const ColdRegs &c, const unsigned word) {
     return make_int4((int)nd, (c.ptc & 0xffff) | (c.fcnt << 16), (c.stt & 0xffff) | (c.ftt << 16), (int)word);
-}
-
-// A UE's record as the event body left it at some subframe s <= t - 1, brought to the start of subframe t: the deferred outcome of
-// subframe s (prach_ue_body.h ue_apply; a caller or matched UE was recorded with txTime = s + 1 already), then the subframes it was
-// matched in since according to the pass word it was scheduled with (sw, kept in the record) — bumped every time, one RAR-window
-// subframe each (Beta.c:245 + the txTime++ of Beta.c:346,358).
-template <class TAB>
-__device__ __forceinline__ void batch_catch_up(UeState &u, const unsigned sw, const bool granted, const int i, const int t, const FastMod fmA, const TAB &tab) {
-    const int tp = t - 1;
-    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) {
-        if (granted) { u.act = ACT_M3; u.tx = tp + 11; u.conn = 0; } // (a grant is applied the very next subframe: s == tp)
-        u.pend = PEND_NONE;
-    } else if (u.pend != PEND_NONE) {
-        ue_apply(u, granted, i, tp, fmA, tab); // (PEND_RESET / PASSIVE / RJOIN are always looked at the very next subframe)
-    } else if (granted) { // a matched UE that was its bucket's only member and called (Beta.c:332-343)
-        u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
-    }
-    const int stj = (int)(sw & 0xFFFFu), sdur = (int)((sw >> 16) & 0x3Fu);
-    if (sdur > 0 && t > stj) { u.rar += t - stj; if (!granted) u.tx = t; } // (a granted UE counted its window subframes too: Beta.c:245 runs before the call)
-}
-
-// the pass word of a UE after the event body of subframe t
-__device__ __forceinline__ unsigned batch_schedule(UeState &u, const int t, const int maxRar) {
-    if (u.act == ACT_DONE) return PW_DONE;
-    if (u.act == ACT_M3) return u.tx > t ? pw_make(u.tx, 0, 0) : PW_IDLE; // Msg3 / Msg4 at txTime (a txTime in the past never comes: Beta.c:167)
-    if (u.pend == PEND_RESET || u.pend == PEND_PASSIVE || u.pend == PEND_RJOIN) return pw_make(t + 1, 0, 0); // outcome needs the caller tables of t
-    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) u.tx = t + 1; // bumped, collided, or singleton without a grant (a grant: bit 31)
-    // The clean cases: asleep until txTime (nowBackoff runs out exactly then: every reschedule sets nowBackoff = txTime - time,
-    // Beta.c:279,305,399) or contending from the next subframe on (nowBackoff <= 0); from txTime on the UE is matched and counts its
-    // RAR window (Beta.c:245) until the window closes.  Anything else (never seen with the reference's parameters) is simply looked
-    // at again in the next subframe by the full body.
-    const bool clean = u.tx > t && (u.bo > 0 ? u.bo == u.tx : u.tx == t + 1);
-    if (!clean) return pw_make(t + 1, 0, u.pre - 1);
-    return pw_make(u.tx, max(0, maxRar - 1 - u.rar), u.pre - 1);
 }
 
 } // namespace
@@ -361,7 +320,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 UeState u = unpack(R.a);
                 ColdRegs cold = cold_unpack(R.b);
                 unsigned nd = (unsigned)R.b.x;
-                if (v) batch_catch_up(u, (unsigned)R.b.w, granted, i, t, K.fmA, tab);
+                if (v) pw_catch_up(u, (unsigned)R.b.w, granted, i, t, K.fmA, tab);
                 if (v && i >= prevAC && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
                     ue_activate(u, i, t, cold);
                     if (withnoma) nd = 2;
@@ -395,7 +354,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                     }
                 }
                 if (v) {
-                    const unsigned word = batch_schedule(u, t, K.maxRar);
+                    const unsigned word = pw_schedule<false>(u, t, K.maxRar);
                     brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, cold, word));
                     pw[i] = word;
                 }
@@ -628,7 +587,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             UeState u = unpack(R.a);
             const ColdRegs cold = cold_unpack(R.b);
             if (status == PRACH_OK && tlast >= 0 && u.act != ACT_IDLE)
-                batch_catch_up(u, (unsigned)R.b.w, (int)__hip_atomic_load(pw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0, i, tend, K.fmA, tab);
+                pw_catch_up(u, (unsigned)R.b.w, (int)__hip_atomic_load(pw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0, i, tend, K.fmA, tab);
             const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
             if (u.act == ACT_DONE) { sumT += timer; ptcS += cold.ptc; fcS += cold.fcnt; }
             ndS += (unsigned)R.b.x;

@@ -476,6 +476,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             for (int q = 0; q < 20; q++) if (names[q][0] != '-') std::fprintf(stderr, " %s=%.0f", names[q], dr.fstamps[q] / (double)dr.steps);
             std::fprintf(stderr, "\n");
         }
+        if (dr.status != PRACH_OK && e->last.rec_mode == CLUSTER_REC_LFAST && std::getenv("PRACH_VERBOSE"))
+            std::fprintf(stderr, "[prach] lcluster_kernel: trial nUE=%d left at subframe %d with status %d, capacity code %d\n", c.nUE, dr.time_exit, dr.status, dr.hard_error);
         if (dr.status == PRACH_ERR_INTERNAL && e->last.rec_mode == CLUSTER_REC_BATCH && std::getenv("PRACH_VERBOSE"))
             std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d left at subframe %d: capacity %d (1 events, 2 reset-cycle candidates, 3 singleton callers, 4 crossing bin)\n", c.nUE, dr.time_exit, dr.hard_error);
         if (dr.status != PRACH_OK) continue;

@@ -195,6 +195,66 @@ __device__ __forceinline__ UeOut ue_select(UeState &u, const UePlan &pl, const i
     return o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PASS WORDS (prach_batch.hip, prach_lcluster.hip): what the per-subframe walk reads of a UE — one 32-bit word, written by the event
+// body when it schedules the UE:
+//     [15:0]  tj   subframe from which the UE is matched by preambleCollision scans (its txTime)               0xFFFF: never
+//     [21:16] dur  number of subframes it then contends with its RAR window open (Beta.c:245): matched in [tj, tj + dur)
+//     [22]    TENT the UE called in the subframe it was scheduled in: whether it is matched from tj on depends on that subframe's
+//                  resolver (a grant takes it out).  A walk that runs AHEAD of that resolver hands it to the body instead
+//     [23]    MB   it was matched in the subframe it was scheduled in (PEND_STAY): "matched before" from its first subframe on
+//     [29:24] preamble       [30] finished for good       [31] UL grant (set by the resolver with one atomicOr)
+// A UE in steady contention is bumped every subframe (Beta.c:346,358) and counts one RAR-window subframe each time (Beta.c:245), so
+// its trajectory until the window closes is known when it is scheduled; the walk only counts it into its bucket.  A UE whose time
+// has come (t == tj + dur: window expiry, Msg3, a deferred outcome) or that got a grant is an EVENT for the body.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr unsigned PW_IDLE = 0x0000FFFFu;  // not arrived yet
+constexpr unsigned PW_DONE = 0x4000FFFFu;  // finished for good
+constexpr unsigned PW_GRANT = 0x80000000u, PW_TENT = 0x00400000u, PW_MB = 0x00800000u;
+constexpr int PW_MAX_RAR = 64, PW_MAX_PREAMBLES = 64, PW_MAX_SUBFRAMES = 65000;
+__device__ __forceinline__ unsigned pw_make(const int tj, const int dur, const int pre) {
+    return ((unsigned)tj & 0xFFFFu) | ((unsigned)dur << 16) | ((unsigned)pre << 24);
+}
+
+// A UE's record as the event body left it at some subframe s <= t - 1, brought to the start of subframe t: the deferred outcome of
+// subframe s (ue_apply; a caller or matched UE was recorded with txTime = s + 1 already), then the subframes it was matched in since
+// according to the pass word it was scheduled with (sw) — bumped every time, one RAR-window subframe each.
+template <class TAB>
+__device__ __forceinline__ void pw_catch_up(UeState &u, const unsigned sw, const bool granted, const int i, const int t, const FastMod fmA, const TAB &tab) {
+    const int tp = t - 1;
+    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) {
+        if (granted) { u.act = ACT_M3; u.tx = tp + 11; u.conn = 0; } // (a grant is applied the very next subframe: s == tp)
+        u.pend = PEND_NONE;
+    } else if (u.pend != PEND_NONE) {
+        ue_apply(u, granted, i, tp, fmA, tab); // (PEND_RESET / PASSIVE / RJOIN are always looked at the very next subframe)
+    } else if (granted) { // a matched UE that was its bucket's only member and called (Beta.c:332-343)
+        u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
+    }
+    const int stj = (int)(sw & 0xFFFFu), sdur = (int)((sw >> 16) & 0x3Fu);
+    if (sdur > 0 && t > stj) { u.rar += t - stj; if (!granted) u.tx = t; } // (a granted UE counted its window subframes too: Beta.c:245 runs before the call)
+}
+
+// the pass word of a UE after the event body of subframe t.  FLAGS: mark callers TENT and matched UEs MB (for a walk that runs ahead
+// of the resolver: prach_lcluster.hip)
+template <bool FLAGS>
+__device__ __forceinline__ unsigned pw_schedule(UeState &u, const int t, const int maxRar) {
+    if (u.act == ACT_DONE) return PW_DONE;
+    if (u.act == ACT_M3) return u.tx > t ? pw_make(u.tx, 0, 0) : PW_IDLE; // Msg3 / Msg4 at txTime (a txTime in the past never comes: Beta.c:167)
+    if (u.pend == PEND_RESET || u.pend == PEND_PASSIVE || u.pend == PEND_RJOIN) return pw_make(t + 1, 0, 0); // outcome needs the caller tables of t
+    unsigned flags = 0u;
+    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) {
+        u.tx = t + 1; // bumped, collided, or singleton without a grant (a grant: bit 31)
+        if (FLAGS) flags = u.pend == PEND_CALLER ? PW_TENT : PW_MB;
+    }
+    // The clean cases: asleep until txTime (nowBackoff runs out exactly then: every reschedule sets nowBackoff = txTime - time,
+    // Beta.c:279,305,399) or contending from the next subframe on (nowBackoff <= 0); from txTime on the UE is matched and counts its
+    // RAR window (Beta.c:245) until the window closes.  Anything else (never seen with the reference's parameters) is simply looked
+    // at again in the next subframe by the full body.
+    const bool clean = u.tx > t && (u.bo > 0 ? u.bo == u.tx : u.tx == t + 1);
+    if (!clean) return pw_make(t + 1, 0, u.pre - 1);
+    return pw_make(u.tx, max(0, maxRar - 1 - u.rar), u.pre - 1) | flags;
+}
+
 // resolver-side info word of a special event (20 bits): type[2:0] ispre[3] bucket p[11:4] old bucket q[19:12]
 __device__ __forceinline__ int ue_event_info(const UeOut &o) {
     const int ispre = (o.evtype == UEV_CALLER) ? (o.member_pre && o.oldp == o.evp) : (o.evtype == UEV_RESETCAND ? (o.evp == o.evq) : 0);
