@@ -93,8 +93,39 @@ def cpu_reference_baseline(budget_s: float):
                 "sample": "oracle/_ref/RandomAccessSimulatorBeta (reference as committed, 54 grants, seed 0): nUE points "
                           + ",".join(str(n) for n, _ in done) + f" of its own hard-coded sweep, {secs:.1f} s of clock(); the program cannot "
                           "be started at nUE=100 000 — its O(N^2) collision scan makes that point slower per update",
-                "at_nUE_100000_measured_in_build_container": {"value": 3.8e6, "unit": "UE-subframe updates/s", "cores": 1,
-                                                              "source": "SURVEY.md §6: the reference's own 100k point, 263 s, same binary"}}
+                "at_nUE_100000": None}  # (filled in by the caller: cpu_reference_at_100k)
+
+
+REF100K_RECORD = os.path.join(ROOT, "profiles", "r03_cpu_reference_100k.json")
+
+
+def cpu_reference_at_100k(full: bool):
+    """The reference's CPU path AT THE METRIC'S OWN SIZE: oracle/_ref/RandomAccessSimulatorBeta_100k is RandomAccessSimulatorBeta.c
+    compiled with its hard-coded sweep started at nUE = 100 000 (oracle/Makefile SED_BETA_100K: one token of line 71), i.e. the
+    reference's own 100 000-UE point from srand(0) — about five minutes on one core, so it only runs with --cpu-full; a default run
+    carries the record of the last such run on a GPU box (profiles/r03_cpu_reference_100k.json), or says that there is none."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "RandomAccessSimulatorBeta_100k")
+    if full and os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as d:
+            os.makedirs(os.path.join(d, "BasicBetaSimulationResults"))
+            t0 = time.perf_counter()
+            p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            wall = time.perf_counter() - t0
+            lines = open(os.path.join(d, "BasicBetaSimulationResults", "0_54_100000_Results.txt")).read().split("\n")
+            tsim = [int(l.split(":")[1].replace("ms", "")) for l in p.stdout.split("\n") if l.startswith("Total simulation time:")][0]
+            steps = min(10000, tsim + 1)
+            rec = {"value": 100000.0 * steps / float(lines[5]), "unit": "UE-subframe updates/s", "cores": 1, "kind": "reference",
+                   "sample": f"oracle/_ref/RandomAccessSimulatorBeta_100k: the reference's nUE = 100 000 point alone from srand(0), {steps} subframes, "
+                             f"{float(lines[5]):.1f} s of clock() ({wall:.1f} s wall), success ratio {lines[1]} %",
+                   "measured_in_this_run": True, "host": os.uname().nodename, "host_cores": host_cores()}
+            return rec
+    if os.path.exists(REF100K_RECORD):
+        rec = json.load(open(REF100K_RECORD))
+        rec["measured_in_this_run"] = False
+        rec["source"] = "profiles/r03_cpu_reference_100k.json: `python bench.py --cpu-full` on a GPU box in round 3"
+        return rec
+    return {"value": 3.8e6, "unit": "UE-subframe updates/s", "cores": 1, "measured_in_this_run": False,
+            "source": "SURVEY.md §6: the reference's own 100k point, 263 s in the build container, same binary (no --cpu-full record yet)"}
 
 
 def cpu_port_all_cores(ob, nue: int, ntrials: int):
@@ -167,6 +198,7 @@ def main():
     ap.add_argument("--workload", choices=("auto", "single", "grid"), default="auto", help="auto: single trial at N=1, the sharded grid at N>1")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of reference-CPU timing (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="also run the reference binary's own nUE = 100 000 point to the end (about five minutes on one core)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -441,13 +473,12 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
             # prach::noma_kernel loads and stores a UE's 16-byte record ONCE per 5 ms access slot (NOMA.c:665-711 runs the grouping per slot
             # and the four subframes behind it on registers), so its own bytes are per UE-SLOT, not per update: 16 B in + 16 B out.
             own = 32.0 * ue_slots
-            return {"bound": "hbm", "achieved": ALGO_BYTES_PER_UPDATE * upd / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ALGO_BYTES_PER_UPDATE * upd / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            return {"bound": "hbm", "achieved": own / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": own / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                     "kernel": f"prach::noma_kernel, {tm_.cluster_size} workgroup(s) per trial", "kernel_ms": kms,
-                    "own_bytes": own, "own_GBps": own / (kms * 1e-3) / 1e9, "own_bytes_per_update": own / upd,
-                    "note": "achieved = ALGORITHMIC 32 B per UE-subframe update / kernel time; own = 32 B per UE and access slot (the record is loaded and "
-                            "stored once per 5 ms); counter-measured HBM traffic of both launches: profiles/r03_noma.md (the state of a trial stays in L2: "
-                            "50 MB of HBM traffic per 100 000-UE trial) — the kernel is bound by one cross-CU exchange + the per-sector resolve per slot"}
+                    "bytes": "the kernel's own bytes: 32 B per UE and 5 ms access slot (record in + out once per slot)", "own_bytes": own, "own_bytes_per_update": own / upd,
+                    "dense_formulation_GBps_32B_per_update": ALGO_BYTES_PER_UPDATE * upd / (kms * 1e-3) / 1e9,
+                    "note": "counter-measured HBM traffic of both launches: profiles/r03_noma.md (a trial's state stays in L2: 50 MB of HBM traffic per "
+                            "100 000-UE trial, 0.7 TB/s for the batched experiment) — the kernel is bound by one cross-CU exchange + the per-sector resolve per slot, not by bytes"}
         slots = args.nue * ((r.steps + 4) // 5)
         extras["noma_c_single_trial"] = {"kernel_updates_per_s": args.nue * r.steps / (tmn.kernel_ms * 1e-3),
                                          "inclusive_updates_per_s_with_host_activation_tables": args.nue * r.steps / (tmn.total_ms * 1e-3),
@@ -480,7 +511,12 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
                            "sample": f"oracle O(N)/subframe restatement, the full workload (nUE={args.nue}, {ores.steps} subframes), {osec:.1f} s"}
         out["cpu_port_all_cores"] = cpu_port_all_cores(ob, args.nue, 2 * host_cores())
         ref = cpu_reference_baseline(args.cpu_budget)
+        at100k = cpu_reference_at_100k(args.cpu_full)
+        if ref is not None:
+            ref["at_nUE_100000"] = at100k
         out["cpu_baseline"] = ref if ref is not None else out["cpu_port"]
+        if args.cpu_full and at100k.get("measured_in_this_run"):
+            out["cpu_baseline_at_metric_size"] = at100k
     return out
 
 
