@@ -99,9 +99,11 @@ size_t cluster_kernel_lds_bytes(int nP, bool glibc, int lslots);
 constexpr int CLUSTER_REC_G16 = 0, CLUSTER_REC_H8 = 1, CLUSTER_REC_L16 = 2;
 constexpr int CLUSTER_EVW = 512;   // special-event granules per cluster mailbox and subframe
 constexpr int CLUSTER_REC_LFAST = 3; // prach_lcluster.hip: the lean LDS-resident kernel (Philox clusters, nPreamble <= 64)
-size_t lcluster_kernel_lds_bytes(int lslots);
+size_t lcluster_kernel_lds_bytes(int lslots, bool glibc = false, int groups = 0);
+int lcluster_group_capacity(int groups);
+int lcluster_max_groups_glibc();
 int lcluster_max_preambles();
-hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, int xpack, hipStream_t stream);
+hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, int xpack, bool glibc, int groups, hipStream_t stream);
 int lcluster_kernel_blocks_per_cu(int lslots);
 constexpr int CLUSTER_LQCAP = 4096; // LDS-resident clusters: owned UE slots per workgroup at most (= the event queue)
 constexpr size_t CLUSTER_LDS_LIMIT = 160 * 1024; // LDS per CU (MI355X_MICROARCH.md): one LDS-resident cluster workgroup per CU

@@ -222,13 +222,18 @@ static int engine_create_impl(int device, prach_engine **out) {
 // one launch over the trials idx[0..m) (all the same rng_mode); attempt = glibc stream retry level
 // LDS-resident records (prach_cluster.hip REC_L16): a Philox cluster whose owned UE slots (the launch's maximum) fit LDS next to
 // the per-subframe structures.  Returns the slot count per workgroup, 0 = records stay in global memory.
-static int lds_record_slots(const prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, int G, int maxP) {
-    if (G <= 1 || !e->opt_lds_records || e->opt_dense || cfgs[idx[0]].rng_mode != PRACH_RNG_PHILOX || cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) return 0;
+static int lds_record_slots(const prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, int G, int maxP, int *maxgroups) {
+    *maxgroups = 0;
+    if (G <= 1 || !e->opt_lds_records || e->opt_dense || cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) return 0;
     int lslots = 0;
     for (int k = 0; k < m; k++) {
         const int groups = (cfgs[idx[k]].nUE + 63) / 64;
         lslots = std::max(lslots, (groups + G - 1) / G * 64);
+        *maxgroups = std::max(*maxgroups, groups);
     }
+    if (cfgs[idx[0]].rng_mode == PRACH_RNG_GLIBC) // the reference's rand() stream: only the lean kernel keeps such a cluster's records in LDS
+        return (lslots <= CLUSTER_LQCAP && e->opt_fast && e->opt_pipeline && maxP <= lcluster_max_preambles() && *maxgroups <= lcluster_max_groups_glibc() &&
+                lcluster_kernel_lds_bytes(lslots, true, *maxgroups) <= CLUSTER_LDS_LIMIT) ? lslots : 0;
     return (lslots <= CLUSTER_LQCAP && cluster_kernel_lds_bytes(maxP, false, lslots) <= CLUSTER_LDS_LIMIT) ? lslots : 0;
 }
 // ... on the lean kernel (prach_lcluster.hip): pipelined compacted pass only, nPreamble <= 64
@@ -408,14 +413,16 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             const prach_cfg &c = cfgs[idx[k]];
             compact = (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 64 < 63000;
         }
-        const int lslots = lds_record_slots(e, cfgs, idx, m, G, maxP);
-        const int rec_mode = use_fast_kernel(e, lslots, maxP) ? CLUSTER_REC_LFAST : (lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16));
+        int maxgroups = 0;
+        const int lslots = lds_record_slots(e, cfgs, idx, m, G, maxP, &maxgroups);
+        const bool glibc = rng_mode == PRACH_RNG_GLIBC;
+        const int rec_mode = (glibc ? lslots > 0 : use_fast_kernel(e, lslots, maxP)) ? CLUSTER_REC_LFAST : (lslots > 0 ? CLUSTER_REC_L16 : (compact ? CLUSTER_REC_H8 : CLUSTER_REC_G16));
         e->last.rec_mode = rec_mode;
         // XCD-packed launch (prach_lcluster.hip): each cluster on one XCD, eight clusters side by side — when the clusters of the launch fit
         // the XCDs' CUs that way (budgeted at one workgroup per CU: LDS-resident state fills a CU, the general layouts take more than half)
         const int xpack = e->opt_xcd_pack && !e->pack_off && G > 1 && rec_mode != CLUSTER_REC_H8 && ((m + 7) / 8) * G <= e->num_cus / 8;
         e->last.xcd_packed = xpack;
-        if (rec_mode == CLUSTER_REC_LFAST) HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, xpack, e->stream));
+        if (rec_mode == CLUSTER_REC_LFAST) HIPCHK(launch_lcluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, lslots, xpack, glibc, maxgroups, e->stream));
         else {
             HIPCHK(launch_cluster_kernel(reinterpret_cast<const TrialDev *>(A), m, G, maxP, rng_mode, rec_mode, lslots, xpack, e->stream));
         }

@@ -162,9 +162,15 @@ __device__ __forceinline__ bool l_light(const unsigned pk, const int rx, const i
 // selectPreamble / requestResourceAllocation on own state, bucket bookkeeping, special events).  pc: byte offset of this
 // subframe's parity block; fb: byte offset of the previous subframe's first / last caller tables inside FCALL / LCALL.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsigned *lnd, const int2 *ldraw, const int pc, const int fb, const int t, const int prevAC,
+// MODE 0: Philox, fused (apply + activate + select).  The reference's own rand() stream (GLIBC) splits it as prach_cluster.hip does: MODE 1 apply +
+// activate + this UE's rand() calls into its group's total and two per-group lane masks (the count follows from the pre-step state);
+// MODE 2, behind the exchange of the counts: select with the draws at stream[sbase + gpre[group] + draws of the lower lanes of the group].
+struct LG { int *gsum; const int *gpre; unsigned *gmask; const PRACH_G int *stream; unsigned long long sbase; }; // (GLIBC only)
+template <int MODE>
+__device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsigned *lnd, const int2 *ldraw, const LG &GL, const int pc, const int fb, const int t, const int prevAC,
                                        PRACH_G long long *mbev, const unsigned tag, const int lane, const int i, const int slot, const bool valid, const int4 r,
                                        unsigned ndc, int &c_succ, int &c_contf) {
+    constexpr bool COUNT = MODE == 1, SELECT = MODE == 2;
     const int nUE = K.nUE;
     const int tp = t - 1;
     const int tmod = fastmod(t, K.fmA);
@@ -177,19 +183,37 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
     UeState u = unpack(r);
 
     // ---- deferred outcome of subframe t-1 (prach_ue_body.h ue_apply) ----
-    if (u.pend != PEND_NONE) {
+    if (!SELECT && u.pend != PEND_NONE) {
         if (u.pend == PEND_STAY) { u.rar += tp - u.tx; u.tx = tp; } // (the record dates from subframe u.tx: compact phase A)
         dirty = ue_apply(u, ((unsigned)r.w & PK_GRANT_BIT) != 0u, i, tp, K.fmA, CallTables{LI(lo::FCALL + fb), LI(lo::LCALL + fb)});
     }
     // ---- activation (Beta.c:136-146; activateUEs' two draws, WithNOMA:393-394, are never looked at: a WithNOMA UE's draw index STARTS at 2) ----
-    if (valid && i >= prevAC) { ue_activate(u, i, t, cold); dirty = true; }
+    if (!SELECT && valid && i >= prevAC) { ue_activate(u, i, t, cold); dirty = true; }
     const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
     const int need = pl.need;
+    const int jl = slot >> 6, ln = slot & 63; // this workgroup's local group of the UE, its lane in the group
+    if (COUNT) {
+        if (need >= 1) {
+            atomicAdd(&GL.gsum[i >> 6], need);
+            atomicOr(&GL.gmask[4 * jl + (ln >> 5)], 1u << (ln & 31));
+            if (need == 2) atomicOr(&GL.gmask[4 * jl + 2 + (ln >> 5)], 1u << (ln & 31));
+        }
+        if (dirty) lrec[slot] = pack(u);
+        return;
+    }
 
     // The next two draws of a UE (Philox counters nd, nd + 1) were computed AHEAD, off the subframe's critical chain (refill in
     // the exchange window), and wait in LDS; a UE whose refill did not fit the list draws in place.
     int d1 = 0, d2 = 0;
-    if (__any(need > 0)) {
+    if (SELECT) { // the reference's own stream: the UE's position inside its group from the two lane masks
+        if (need > 0) {
+            const unsigned lo_ = ln < 32 ? (1u << ln) - 1u : 0xffffffffu, hi_ = ln < 32 ? 0u : (1u << (ln - 32)) - 1u;
+            const int before = __popc(GL.gmask[4 * jl] & lo_) + __popc(GL.gmask[4 * jl + 1] & hi_) + __popc(GL.gmask[4 * jl + 2] & lo_) + __popc(GL.gmask[4 * jl + 3] & hi_);
+            const unsigned long long o = GL.sbase + (unsigned long long)GL.gpre[i >> 6] + (unsigned long long)before;
+            d1 = GL.stream[o];
+            if (need > 1) d2 = GL.stream[o + 1];
+        }
+    } else if (__any(need > 0)) {
         const unsigned k = ndc;
         if (need > 0 && rdy) { const int2 dd = ldraw[slot]; d1 = dd.x; d2 = dd.y; }
         if (__any(need > 0 && !rdy)) {
@@ -213,7 +237,7 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
     {
         // special events -> this workgroup's mailbox, early-leaver candidates and refills -> their lists: the three list positions are
         // taken by lane 0 with three returning LDS atomics issued back to back — ONE wait instead of three dependent round trips
-        const unsigned long long em = __ballot(evtype != 0), cm = __ballot(eclass), rm = __ballot(need > 0);
+        const unsigned long long em = __ballot(evtype != 0), cm = __ballot(eclass), rm = SELECT ? 0ull : __ballot(need > 0);
         if (em | cm | rm) {
             int b_ev = 0, b_cd = 0, b_rq = 0;
             if (lane == 0) {
@@ -233,13 +257,13 @@ __device__ __forceinline__ void l_step(char *smem, const LK &K, int4 *lrec, unsi
                 else LI(lo::SCAL)[S_STATUS] = PRACH_ERR_INTERNAL; // (engine: exact rerun on the general kernels)
                 atomicAdd(&candn[oldp], 1);
             }
-            if (need > 0) {
+            if (!SELECT && need > 0) {
                 const int rs = b_rq + __popcll(rm & lanemask_lt(lane));
                 if (rs < LRQ) LI(lo::RQ)[rs] = slot;
             }
         }
     }
-    if (nd_dirty) lnd[slot] = ndc | (rdy ? ND_READY : 0u);
+    if (!SELECT && nd_dirty) lnd[slot] = ndc | (rdy ? ND_READY : 0u);
     if (dirty) lrec[slot] = pack(u);
 }
 
@@ -299,7 +323,9 @@ __device__ __forceinline__ void l_resolve_reset_candidates(char *smem, const int
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots, const int xpack, const int ntrials) {
+// GLIBC: the reference's own rand() stream (window PD->stream, generated on the device before this launch); gcap = groups the LDS count tables hold
+template <bool GLIBC>
+__global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__restrict__ params, const int G, const int lslots, const int xpack, const int ntrials, const int gcap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int T = blockIdx.x / G, b = blockIdx.x % G; // a cluster = consecutive blocks (in-order dispatch completes whole clusters)
     if (xpack) {
@@ -335,8 +361,16 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     const bool withnoma = K.withnoma;
 
     int4 *const lrec = reinterpret_cast<int4 *>(smem + lo::TAIL);
-    int2 *const ldraw = reinterpret_cast<int2 *>(smem + lo::TAIL + 16 * lslots);
-    unsigned *const lnd = reinterpret_cast<unsigned *>(smem + lo::TAIL + 24 * lslots);
+    // Philox: draw index + the next two draws per slot.  GLIBC: instead, rand() calls of every 64-UE group of the trial in this subframe
+    // (gsum), their exclusive prefix in index order (gpre), and per OWN group the lanes that draw once or twice / twice (gmask)
+    int2 *const ldraw = GLIBC ? nullptr : reinterpret_cast<int2 *>(smem + lo::TAIL + 16 * lslots);
+    unsigned *const lnd = GLIBC ? nullptr : reinterpret_cast<unsigned *>(smem + lo::TAIL + 24 * lslots);
+    int *const gsum = reinterpret_cast<int *>(smem + lo::TAIL + 16 * lslots), *const gpre = gsum + gcap;
+    unsigned *const gmask = reinterpret_cast<unsigned *>(gpre + gcap); // [4 * lslots / 64]
+    const PRACH_G int *const stream = (const PRACH_G int *)PD->stream;
+    const unsigned long long stream_len = PD->stream_len;
+    unsigned long long base = 0; // GLIBC: rand() calls consumed so far (relative to the stream window)
+    int qn_glibc = 0;
     int *const scal = LI(lo::SCAL);
     int *const queue = LI(lo::QUEUE);
     int2 *const gev = LI2(lo::GEV);
@@ -374,16 +408,23 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     // calloc + initialUE (Beta.c:78-83) for the groups this workgroup owns
     const unsigned nd0 = K.withnoma ? 2u : 0u; // activateUEs draws twice before the first preamble draw (WithNOMA:393-394)
     for (int x = tid; x < lslots; x += WG_THREADS) {
-        lrec[x] = make_int4(-1, 0, 0, 0); lnd[x] = nd0; // (every slot, also past the last UE)
+        lrec[x] = make_int4(-1, 0, 0, 0); // (every slot, also past the last UE)
+        if (!GLIBC) lnd[x] = nd0;
         if (x < lgroups * 64) {
             const int g = b + G * (x >> 6), i = g * 64 + (x & 63);
             if (g < totgroups && i < nUE) {
                 K.ptc[i] = 0; K.ftt[i] = 0; K.stt[i] = 0; K.fcnt[i] = 0;
-                ldraw[x] = make_int2(philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd0, (unsigned)K.nUE, (unsigned)K.variant),
-                                     philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd0 + 1u, (unsigned)K.nUE, (unsigned)K.variant));
-                lnd[x] = nd0 | ND_READY;
+                if (!GLIBC) {
+                    ldraw[x] = make_int2(philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd0, (unsigned)K.nUE, (unsigned)K.variant),
+                                         philox_draw31(K.seed_lo, K.seed_hi, (unsigned)i, nd0 + 1u, (unsigned)K.nUE, (unsigned)K.variant));
+                    lnd[x] = nd0 | ND_READY;
+                }
             }
         }
+    }
+    if (GLIBC) {
+        for (int g = tid; g < gcap; g += WG_THREADS) { gsum[g] = 0; gpre[g] = 0; }
+        for (int x = tid; x < 4 * (lslots >> 6); x += WG_THREADS) gmask[x] = 0u;
     }
     if (tid < NPCL) {
 #pragma unroll
@@ -421,7 +462,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
     unsigned long long steps = 0;
-    int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || G > 64 || lgroups > 64 * NWA || stop >= 0xFFFE) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (lgroups * 64 > lslots || lslots > LQ || nP > NPCL || (GLIBC && totgroups > gcap) || G > 64 || lgroups > 64 * NWA || stop >= 0xFFFE) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
     unsigned long long deadmask = 0; // bit m: this wavefront's m-th group (local group w + NWA * m) is finished for good
     int t5 = 0, tA = 0, slotA = 0;   // t mod 5, t mod accessTime, t / accessTime: kept incrementally
     // arrival table entry of the NEXT access slot: fetched one slot ahead by a VECTOR load whose result is only made scalar
@@ -578,15 +619,83 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             const int sl_first = queue[w * 64 + lane]; // (read together with the queue length: one LDS round trip, not two)
             const int qn = scal[S_QN + parity];
             LSTAT(0, qn);
-            for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
-                const bool v = q0 + lane < qn;
-                const int sl = v ? (q0 == w * 64 ? sl_first : queue[q0 + lane]) : 0;
-                const int i = l_idx_of(K, sl);
-                int4 r = make_int4(-1, 0, 0, 0);
-                unsigned ndc = 0;
-                if (v) { r = lrec[sl]; ndc = lnd[sl]; }
-                // (an idle lane keeps the idle record: l_step leaves it alone)
-                l_step(smem, K, lrec, lnd, ldraw, pc, fb, t, prevAC, mbev, tag, lane, i, sl, v && i < activeCheck, r, ndc, c_succ, c_contf);
+            const LG GL0{nullptr, nullptr, nullptr, nullptr, 0ull};
+            if (!GLIBC) {
+                for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
+                    const bool v = q0 + lane < qn;
+                    const int sl = v ? (q0 == w * 64 ? sl_first : queue[q0 + lane]) : 0;
+                    const int i = l_idx_of(K, sl);
+                    int4 r = make_int4(-1, 0, 0, 0);
+                    unsigned ndc = 0;
+                    if (v) { r = lrec[sl]; ndc = lnd[sl]; }
+                    // (an idle lane keeps the idle record: l_step leaves it alone)
+                    l_step<0>(smem, K, lrec, lnd, ldraw, GL0, pc, fb, t, prevAC, mbev, tag, lane, i, sl, v && i < activeCheck, r, ndc, c_succ, c_contf);
+                }
+            } else {
+                // The reference's own stream: every draw's position = rand() calls of earlier subframes + this subframe's activation draws
+                // (activateUEs, WithNOMA:393-394) + the index-ordered prefix of per-UE call counts.  Count pass over the queued UEs, exchange of
+                // the per-group counts (two per granule, behind the event granules of the mailbox), block-wide prefix, select pass.
+                const unsigned long long actdraws = withnoma ? 2ull * (unsigned long long)(activeCheck - prevAC) : 0ull;
+                const int ngroups_t = (activeCheck + 63) >> 6;
+                const LG GC{gsum, gpre, gmask, stream, 0ull};
+                for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
+                    const bool v = q0 + lane < qn;
+                    const int sl = v ? (q0 == w * 64 ? sl_first : queue[q0 + lane]) : 0;
+                    const int i = l_idx_of(K, sl);
+                    int4 r = make_int4(-1, 0, 0, 0);
+                    if (v) r = lrec[sl];
+                    l_step<1>(smem, K, lrec, lnd, ldraw, GC, pc, fb, t, prevAC, mbev, tag, lane, i, sl, v && i < activeCheck, r, 0u, c_succ, c_contf);
+                }
+                __syncthreads(); // the counts of this workgroup's groups are complete
+                {
+                    const int nq = (lgroups + 4) / 5;
+                    PRACH_G long long *const mine = mygr + 1 + nP + CLUSTER_EVW;
+                    for (int q = tl; q < nq; q += WG_THREADS) {
+                        unsigned c5[5];
+#pragma unroll
+                        for (int u_ = 0; u_ < 5; u_++) { const int g = b + G * (5 * q + u_); c5[u_] = g < totgroups ? (unsigned)gsum[g] : 0u; }
+                        lstx(sx, mine + q, lmk(c5[0] | (c5[1] << 8) | ((c5[2] & 0xFu) << 16), (c5[2] >> 4) | (c5[3] << 4) | (c5[4] << 12), tag));
+                    }
+                    // (five 8-bit counts per granule — a 64-UE group makes at most 128 calls: fewer granules, fewer pollers.  Gathering them directly
+                    //  into the scanning threads' registers, four polls per thread and no staging barrier, measured 2.5 ms SLOWER per trial:
+                    //  4096 pollers per workgroup get in the way of the stores they wait for)
+                    for (int k = tl; k < G * nq; k += WG_THREADS) {
+                        const int wg = k / nq, q = k - wg * nq;
+                        if (wg == b) continue;
+                        const long long g_ = lwait(mbpar + (unsigned)wg * mbs + 1u + (unsigned)nP + (unsigned)CLUSTER_EVW + (unsigned)q, tag, smem);
+                        const unsigned lo_ = (unsigned)g_ & 0xFFFFFu, hi_ = (unsigned)((unsigned long long)g_ >> 32) & 0xFFFFFu;
+                        const unsigned c5[5] = {lo_ & 0xFFu, (lo_ >> 8) & 0xFFu, (lo_ >> 16) | ((hi_ & 0xFu) << 4), (hi_ >> 4) & 0xFFu, (hi_ >> 12) & 0xFFu};
+#pragma unroll
+                        for (int u_ = 0; u_ < 5; u_++) { const int g = wg + G * (5 * q + u_); if (g < totgroups) gsum[g] = (int)c5[u_]; }
+                    }
+                    __syncthreads();
+                    int vv[4], sum = 0;
+#pragma unroll
+                    for (int u_ = 0; u_ < 4; u_++) { const int g = tl * 4 + u_; vv[u_] = g < ngroups_t ? gsum[g] : 0; sum += vv[u_]; }
+                    const int x = wave_scan_incl(sum);
+                    if (lane == 63) LI(lo::WTOT)[w] = x;
+                    __syncthreads();
+                    int run = x - sum;
+                    for (int k = 0; k < w; k++) run += LI(lo::WTOT)[k];
+#pragma unroll
+                    for (int u_ = 0; u_ < 4; u_++) { const int g = tl * 4 + u_; if (g < gcap) gpre[g] = run; run += vv[u_]; }
+                    if (tl == WG_THREADS - 1) scal[S_NCROSS] = run; // (free here: only the grant selection uses it)
+                }
+                __syncthreads();
+                const unsigned long long tot = actdraws + (unsigned long long)scal[S_NCROSS];
+                if (scal[S_STATUS] != PRACH_OK) { status = scal[S_STATUS]; time_exit = t; break; }
+                if (base + tot > stream_len) { status = PRACH_ERR_STREAM; time_exit = t; break; } // (the engine retries with a larger window)
+                const LG GS{gsum, gpre, gmask, stream, base + actdraws};
+                for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
+                    const bool v = q0 + lane < qn;
+                    const int sl = v ? queue[q0 + lane] : 0;
+                    const int i = l_idx_of(K, sl);
+                    int4 r = make_int4(-1, 0, 0, 0);
+                    if (v) r = lrec[sl];
+                    l_step<2>(smem, K, lrec, lnd, ldraw, GS, pc, fb, t, prevAC, mbev, tag, lane, i, sl, v && i < activeCheck, r, 0u, c_succ, c_contf);
+                }
+                base += tot;
+                qn_glibc = qn;
             }
             if (__any((c_succ | c_contf) != 0)) {
                 const int ss_ = wave_sum(c_succ), sf_ = wave_sum(c_contf);
@@ -599,6 +708,15 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         LSTAMP(1); // phase B
         __syncthreads(); // S1: histogram / lowest callers / candidate list of this workgroup are complete; [B] is free
         LSTAMP(2);
+        if (GLIBC) {
+            // every draw of this subframe has been read: the counts of the groups the queued UEs are in can go (own groups only ever get counts
+            // from this workgroup; nobody looks at them again before the count pass of the next subframe, several barriers from here)
+            for (int q = tl; q < qn_glibc; q += WG_THREADS) {
+                const int sl = queue[q], jl = sl >> 6;
+                gsum[l_idx_of(K, sl) >> 6] = 0; gmask[4 * jl] = 0u; gmask[4 * jl + 1] = 0u; gmask[4 * jl + 2] = 0u; gmask[4 * jl + 3] = 0u;
+            }
+            // (pulling the part of the stream window the next subframes draw from into L2 ahead of time, one slice per workgroup: 0.6 ms slower)
+        }
         // publish, first part: per bucket {histogram, lowest caller} — complete since S1; the header (event count) follows the leaver
         // filter.  Self-validating granules: the earlier they leave, the fewer of them the other workgroups have to read twice.
         if (tl >= WG_THREADS - 64 && tl - (WG_THREADS - 64) < nP) { // (the last wavefront: the first ones run the leaver filter)
@@ -659,7 +777,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         for (int u = 0; u < 2; u++)
             if (r2wg[u] >= 0) ev2[u] = lld(mbpar + r2off[u]);
         LSTAMP(17);
-        { // refill: the next two draws of every UE that drew in this subframe's phase B (off the chain: the exchange is in flight)
+        if (!GLIBC) { // refill: the next two draws of every UE that drew in this subframe's phase B (off the chain: the exchange is in flight)
             const int nrq = min(scal[S_NRQ], LRQ);
             LSTAT(3, scal[S_NRQ]);
             for (int k = (tl + WG_THREADS / 2) & (WG_THREADS - 1); k < nrq; k += WG_THREADS) { // (from wavefront 8 on: wavefront 0 has the deferred calls)
@@ -895,7 +1013,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
             const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
             const int ptc = K.ptc[i], fc = K.fcnt[i];
             if (u.act == ACT_DONE) { sumT += timer; ptcS += ptc; fcS += fc; }
-            if (u.act != ACT_IDLE) ndS += lnd[x] & ~ND_READY; // (a UE that never arrived drew nothing)
+            if (!GLIBC && u.act != ACT_IDLE) ndS += lnd[x] & ~ND_READY; // (a UE that never arrived drew nothing)
             timers[i] = u.act == ACT_DONE ? timer : INT_MIN;
             if (logs) {
                 prach_ue_log o;
@@ -922,7 +1040,8 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     if (tid == 0) { // DevResult was zeroed by the engine before the launch
         PRACH_G DevResult *o = (PRACH_G DevResult *)PD->out;
         gadd(&o->sumTimer, *reinterpret_cast<long long *>(&scal[S_SUMT]));
-        gadd(&o->draws, *reinterpret_cast<unsigned long long *>(&scal[S_ND]));
+        if (GLIBC) { if (b == 0) gadd(&o->draws, base); } // (every workgroup has counted the same stream position)
+        else gadd(&o->draws, *reinterpret_cast<unsigned long long *>(&scal[S_ND]));
         gadd(&o->ptcSum, scal[S_PTC]);
         gadd(&o->fcSum, scal[S_FC]);
         gadd(&o->nSuccess, scal[S_NSUCC]);
@@ -944,23 +1063,33 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     }
 }
 
-size_t lcluster_kernel_lds_bytes(int lslots) { return (size_t)lo::TAIL + (size_t)lslots * 28; }
+// glibc (the reference's own rand() stream): no draws computed ahead (16 B per slot), but the per-group call counts of the whole trial and
+// their prefix (8 B per group, `groups` rounded up) and four mask words per own group
+size_t lcluster_kernel_lds_bytes(int lslots, bool glibc, int groups) {
+    if (!glibc) return (size_t)lo::TAIL + (size_t)lslots * 28;
+    return (size_t)lo::TAIL + (size_t)lslots * 16 + (size_t)lcluster_group_capacity(groups) * 8 + (size_t)(lslots / 64) * 16;
+}
+int lcluster_group_capacity(int groups) { return (groups + 63) / 64 * 64; }
+int lcluster_max_groups_glibc() { return 4 * WG_THREADS; } // (the block-wide prefix takes 4 groups per thread)
 int lcluster_max_preambles() { return NPCL; }
 
-hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, int xpack, hipStream_t stream) {
-    const size_t lds = lcluster_kernel_lds_bytes(lslots);
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, int xpack, bool glibc, int groups, hipStream_t stream) {
+    const size_t lds = lcluster_kernel_lds_bytes(lslots, glibc, groups);
+    const void *fn = glibc ? reinterpret_cast<const void *>(&lcluster_kernel<true>) : reinterpret_cast<const void *>(&lcluster_kernel<false>);
+    hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
     const int grid = xpack ? ((ntrials + 7) / 8) * 8 * G : ntrials * G;
-    hipLaunchKernelGGL(lcluster_kernel, dim3(grid), dim3(WG_THREADS), lds, stream, params, G, lslots, xpack, ntrials);
+    const int gcap = lcluster_group_capacity(groups);
+    if (glibc) hipLaunchKernelGGL(lcluster_kernel<true>, dim3(grid), dim3(WG_THREADS), lds, stream, params, G, lslots, xpack, ntrials, gcap);
+    else hipLaunchKernelGGL(lcluster_kernel<false>, dim3(grid), dim3(WG_THREADS), lds, stream, params, G, lslots, xpack, ntrials, gcap);
     return hipGetLastError();
 }
 
 int lcluster_kernel_blocks_per_cu(int lslots) {
-    const size_t lds = lcluster_kernel_lds_bytes(lslots);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+    const size_t lds = lcluster_kernel_lds_bytes(lslots, false, 0);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&lcluster_kernel), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&lcluster_kernel<false>), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;
     return nb;
 }
 

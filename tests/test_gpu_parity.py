@@ -286,22 +286,26 @@ def test_xcd_packed_clusters(pkg, ob, engine):
             for c, r, l in zip(cfgs, *engine.run_trials(cfgs, want_logs=True)):
                 ores, oues = ob.run_trial(ob.make_cfg(c.nUE, variant=c.variant), ob.Rng(ob.RNG_PHILOX, int(c.seed)))
                 assert_same(pkg, r, l, ores, oues, ("packed", G, c.nUE))
-        # the general kernel's clusters (the reference's own rand() stream: two exchanges per subframe) launch the same way
+        # clusters in the reference's own rand() stream (two exchanges per subframe) launch the same way: on the lean kernel (round 3: the count
+        # pass / count exchange / select pass on LDS-resident records) and, with engine option "fast" 0, on the general kernel
         engine.set("cluster", 16)
         gcfg = pkg.make_cfg(24000, variant=1, rng_mode=pkg.RNG_GLIBC, seed=3)
-        out = {}
-        for pack in (1, 0):
-            engine.set("xcd_pack", pack)
-            (res,), (logs,) = engine.run_trials([gcfg], want_logs=True)
-            tm = engine.timing()
-            assert tm.rec_mode != 3 and tm.cluster_size == 16 and tm.xcd_packed == pack and tm.fallback_trials == 0, (pack, tm.rec_mode, tm.xcd_packed)
-            out[pack] = (res.as_dict(), bytes(logs))
-        assert out[0] == out[1]
         ores, oues = ob.run_trial(ob.make_cfg(24000, variant=1), ob.Rng(ob.RNG_GLIBC, 3))
-        engine.set("xcd_pack", 1)
-        (res,), (logs,) = engine.run_trials([gcfg], want_logs=True)
-        assert_same(pkg, res, logs, ores, oues, "packed glibc cluster")
+        for fast in (1, 0):
+            engine.set("fast", fast)
+            out = {}
+            for pack in (1, 0):
+                engine.set("xcd_pack", pack)
+                (res,), (logs,) = engine.run_trials([gcfg], want_logs=True)
+                tm = engine.timing()
+                assert (tm.rec_mode == 3) == bool(fast) and tm.cluster_size == 16 and tm.xcd_packed == pack and tm.fallback_trials == 0, (fast, pack, tm.rec_mode, tm.xcd_packed)
+                out[pack] = (res.as_dict(), bytes(logs))
+            assert out[0] == out[1]
+            engine.set("xcd_pack", 1)
+            (res,), (logs,) = engine.run_trials([gcfg], want_logs=True)
+            assert_same(pkg, res, logs, ores, oues, ("packed glibc cluster", fast))
     finally:
+        engine.set("fast", 1)
         engine.set("xcd_pack", 1)
         engine.set("cluster", 0)
 
