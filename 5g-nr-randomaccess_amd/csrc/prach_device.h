@@ -104,7 +104,6 @@ int lcluster_group_capacity(int groups);
 int lcluster_max_groups_glibc();
 int lcluster_max_preambles();
 hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, int lslots, int xpack, bool glibc, int groups, hipStream_t stream);
-int lcluster_kernel_blocks_per_cu(int lslots);
 constexpr int CLUSTER_LQCAP = 4096; // LDS-resident clusters: owned UE slots per workgroup at most (= the event queue)
 constexpr size_t CLUSTER_LDS_LIMIT = 160 * 1024; // LDS per CU (MI355X_MICROARCH.md): one LDS-resident cluster workgroup per CU
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int xpack, hipStream_t stream);

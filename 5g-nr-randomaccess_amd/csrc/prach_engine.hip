@@ -536,7 +536,7 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
     for (int k = 0; k < n; k++) {
         if (cfgs[k].variant != PRACH_VARIANT_NOMA_C || cfgs[k].rng_mode != PRACH_RNG_GLIBC) continue;
         int rc = PRACH_ERR_STREAM;
-        for (int attempt = 0; attempt < 6 && rc == PRACH_ERR_STREAM; attempt++) {
+        for (int attempt = 0; attempt < 4 && rc == PRACH_ERR_STREAM; attempt++) { // (48, 192, 768, 3072 values per UE: 1.2 GB at nUE = 100 000 at most, then PRACH_ERR_STREAM)
             const unsigned long long len = ((unsigned long long)cfgs[k].nUE * 48ull + (1ull << 18)) << (2 * attempt);
             std::vector<int32_t> hs((size_t)len);
             prach_glibc_stream((uint32_t)cfgs[k].seed, cfgs[k].stream_offset, len, hs.data());
@@ -611,7 +611,9 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             int minGroups = INT_MAX;
             for (int k : idx) minGroups = std::min(minGroups, (cfgs[k].nUE + 63) / 64);
             int G = (int)e->opt_cluster;
-            const size_t resident = (size_t)resident_workgroups(e, cluster_kernel_blocks_per_cu(maxP, mode, CLUSTER_REC_G16, 0));
+            // (every cluster layout of this library takes more than half a CU's LDS: one workgroup per CU.  Asked of the runtime for the
+            //  general kernel's smallest layout; the lean kernel and the LDS-resident layouts only ever need more LDS, never admit more)
+            const size_t resident = (size_t)resident_workgroups(e, std::min(cluster_kernel_blocks_per_cu(maxP, mode, CLUSTER_REC_G16, 0), 1));
             e->last.resident_limit = (int32_t)resident;
             if (G <= 0) {
                 G = 1;

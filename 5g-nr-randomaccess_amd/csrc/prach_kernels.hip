@@ -426,7 +426,10 @@ __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__res
         if ((P.flags & PRACH_FLAG_SECTOR_GRANTS) && activeCheck > prevAC) {
             // activateUEs (WithNOMA:393-410): theta from the first of the two activation draws fixes the UE's sector (r is never read)
             for (int i = prevAC + (int)threadIdx.x; i < activeCheck; i += WG_THREADS) {
-                const int d = GLIBC ? P.stream[base + 2ull * (unsigned long long)(i - prevAC)]
+                // (glibc: a position beyond the stream window reads entry 0 instead — the window check below then ends the trial with
+                //  PRACH_ERR_STREAM and the engine reruns it with a larger window, so the value is never used)
+                const unsigned long long so = base + 2ull * (unsigned long long)(i - prevAC);
+                const int d = GLIBC ? P.stream[so < P.stream_len ? so : 0ull]
                                     : philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, 0u, (unsigned)nUE, (unsigned)P.variant);
                 const float pi = 3.14f;
                 const float theta = (float)d / (float)2147483647 * 2 * pi;

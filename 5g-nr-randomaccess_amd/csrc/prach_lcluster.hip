@@ -1085,12 +1085,4 @@ hipError_t launch_lcluster_kernel(const TrialDev *params, int ntrials, int G, in
     return hipGetLastError();
 }
 
-int lcluster_kernel_blocks_per_cu(int lslots) {
-    const size_t lds = lcluster_kernel_lds_bytes(lslots, false, 0);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lcluster_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&lcluster_kernel<false>), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;
-    return nb;
-}
-
 } // namespace prach

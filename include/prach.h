@@ -107,8 +107,9 @@ typedef struct prach_timing {
     int32_t workgroups;   /* workgroups of the last launch */
     uint64_t updates;     /* sum over trials of nUE * steps */
     int32_t cluster_size;    /* workgroups per trial of the last launch (0: the one-workgroup fallback kernel) */
-    int32_t resident_limit;  /* workgroups the runtime's occupancy query admits at once for the cluster kernel and its LDS
-                                size; a cluster launch never exceeds it (its workgroups wait for each other) */
+    int32_t resident_limit;  /* workgroups of a cluster launch that can be resident at once: one per CU (every cluster layout takes
+                                more than half a CU's LDS; the runtime's occupancy query for the smallest one is the upper bound);
+                                a cluster launch never exceeds it (its workgroups wait for each other) */
     int32_t fallback_trials; /* trials of the last call that a cluster launch could not finish and that were rerun (exactly) on
                                 a kernel that waits for nobody: a per-subframe capacity exceeded, or a peer wait timed out.  Philox
                                 trials go to prach::batch_kernel first (one workgroup per trial, event queue without a capacity);
