@@ -98,6 +98,7 @@ constexpr int LCAND = QUEUE + 4 * LQ;           // int2 [LCC]
 constexpr int RQ = BINS;                        // int [LRQ] refill list (phase B .. round 1; BINS is only used by the grant selection)
 constexpr int TAIL = LCAND + 8 * LCC;           // int4 lrec[lslots]; int2 ldraw[lslots]; unsigned lnd[lslots]
 static_assert(LRQ <= LGB, "the refill list shares the grant bins");
+static_assert(LQ <= 4 * WG_THREADS, "at most four queue batches per wavefront (the glibc mode remembers its slots in four registers)");
 static_assert(SIDX % 16 == 0 && TAIL % 16 == 0 && LCAND % 8 == 0, "alignment");
 } // namespace lo
 
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
     const PRACH_G int *const stream = (const PRACH_G int *)PD->stream;
     const unsigned long long stream_len = PD->stream_len;
     unsigned long long base = 0; // GLIBC: rand() calls consumed so far (relative to the stream window)
-    int qn_glibc = 0;
+    int zs[4] = {-1, -1, -1, -1}, nzs = 0; // GLIBC: the slots this lane ran through the select pass (their groups' counts are zeroed behind S1)
     int *const scal = LI(lo::SCAL);
     int *const queue = LI(lo::QUEUE);
     int2 *const gev = LI2(lo::GEV);
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                 if (scal[S_STATUS] != PRACH_OK) { status = scal[S_STATUS]; time_exit = t; break; }
                 if (base + tot > stream_len) { status = PRACH_ERR_STREAM; time_exit = t; break; } // (the engine retries with a larger window)
                 const LG GS{gsum, gpre, gmask, stream, base + actdraws};
+                nzs = 0;
                 for (int q0 = w * 64; q0 < qn; q0 += NW * 64) {
                     const bool v = q0 + lane < qn;
                     const int sl = v ? queue[q0 + lane] : 0;
@@ -693,9 +695,10 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
                     int4 r = make_int4(-1, 0, 0, 0);
                     if (v) r = lrec[sl];
                     l_step<2>(smem, K, lrec, lnd, ldraw, GS, pc, fb, t, prevAC, mbev, tag, lane, i, sl, v && i < activeCheck, r, 0u, c_succ, c_contf);
+                    if (nzs < 4) zs[nzs] = v ? sl : -1; // (remembered in registers: the queue's entries are overwritten by phase A of t + 1 behind S1)
+                    nzs++;
                 }
                 base += tot;
-                qn_glibc = qn;
             }
             if (__any((c_succ | c_contf) != 0)) {
                 const int ss_ = wave_sum(c_succ), sf_ = wave_sum(c_contf);
@@ -711,10 +714,14 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         if (GLIBC) {
             // every draw of this subframe has been read: the counts of the groups the queued UEs are in can go (own groups only ever get counts
             // from this workgroup; nobody looks at them again before the count pass of the next subframe, several barriers from here)
-            for (int q = tl; q < qn_glibc; q += WG_THREADS) {
-                const int sl = queue[q], jl = sl >> 6;
-                gsum[l_idx_of(K, sl) >> 6] = 0; gmask[4 * jl] = 0u; gmask[4 * jl + 1] = 0u; gmask[4 * jl + 2] = 0u; gmask[4 * jl + 3] = 0u;
+#pragma unroll
+            for (int r_ = 0; r_ < 4; r_++) { // (the queue holds at most LQ = 4096 entries: four batches per wavefront)
+                if (r_ < nzs && zs[r_] >= 0) {
+                    const int sl = zs[r_], jl = sl >> 6;
+                    gsum[l_idx_of(K, sl) >> 6] = 0; gmask[4 * jl] = 0u; gmask[4 * jl + 1] = 0u; gmask[4 * jl + 2] = 0u; gmask[4 * jl + 3] = 0u;
+                }
             }
+            nzs = 0;
             // (pulling the part of the stream window the next subframes draw from into L2 ahead of time, one slice per workgroup: 0.6 ms slower)
         }
         // publish, first part: per bucket {histogram, lowest caller} — complete since S1; the header (event count) follows the leaver

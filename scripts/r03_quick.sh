@@ -1,11 +1,4 @@
 set -e
-mkdir -p gpurun_out/r03
-python3 -c "import __graft_entry__ as g; g.smoke()"
-python3 bench.py > gpurun_out/r03/bench_default.json 2> gpurun_out/r03/bench_default.err || { tail -20 gpurun_out/r03/bench_default.err; exit 1; }
-python3 -c "
-import json;d=json.load(open('gpurun_out/r03/bench_default.json'))
-print('value',d['value'],'frac',d['roofline']['frac'],'us',d['roofline']['us_per_subframe'])
-print('glibc',d['extras']['glibc_mode_reference_point'])
-print('cpu',d['cpu_baseline']['value'], d['cpu_baseline']['at_nUE_100000']['value'], d['cpu_baseline']['at_nUE_100000'].get('measured_in_this_run'))
-print('noma', d['extras']['noma_c_experiment_batched']['roofline']['frac'], d['extras']['noma_c_single_trial']['roofline']['frac'])
-"
+python3 tests/tools/gpu_glibc_time.py 2>&1 | grep "xcd_pack=1" | grep glibc | head -3
+python -m pytest tests -m gpu -x -q -k "reproduces_reference_files or random_flags or xcd_packed" 2>&1 | tail -3
+python3 tests/tools/gpu_fuzz.py 72 300 2>&1 | grep -v "^\[prach\]" | tail -1

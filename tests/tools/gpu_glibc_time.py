@@ -3,6 +3,8 @@ sys.path.insert(0, os.getcwd())
 import __graft_entry__ as g
 m = g.load_package()
 eng = m.Engine(0)
+for kv in filter(None, os.environ.get("PRACH_ENG_OPTS", "").split(",")):
+    eng.set(kv.split("=")[0], int(kv.split("=")[1]))
 for variant, nUE in ((0, 100000), (1, 100000), (0, 40000)):
     for pack in (1, 0):
         eng.set("xcd_pack", pack)
