@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 m = g.load_package()
 eng = m.Engine(0)
+for kv in filter(None, os.environ.get("PRACH_ENG_OPTS", "").split(",")):
+    eng.set(kv.split("=")[0], int(kv.split("=")[1]))
 mode = sys.argv[1] if len(sys.argv) > 1 else "single"
 if mode == "single":
     cfgs = [m.make_cfg(100000, variant=m.VARIANT_NOMA_C, rng_mode=m.RNG_PHILOX, seed=0)]

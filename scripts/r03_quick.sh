@@ -1,4 +1,5 @@
 set -e
-python3 tests/tools/gpu_glibc_time.py 2>&1 | grep "xcd_pack=1" | grep glibc | head -3
-python -m pytest tests -m gpu -x -q -k "reproduces_reference_files or random_flags or xcd_packed" 2>&1 | tail -3
-python3 tests/tools/gpu_fuzz.py 72 300 2>&1 | grep -v "^\[prach\]" | tail -1
+for G in 0 2 4; do
+echo "cluster=$G"
+PRACH_ENG_OPTS=cluster=$G python3 scripts/gpu_noma_batch.py batch 10 2>&1 | tail -1 | cut -c1-260
+done
