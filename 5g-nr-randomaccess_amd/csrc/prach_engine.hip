@@ -619,7 +619,9 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             e->last.resident_limit = (int32_t)resident;
             if (G <= 0) {
                 G = 1;
-                while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident / 2 && G * 2 <= std::max(1, minGroups / 16)) G *= 2;
+                // (the clusters of a call may fill the CUs: 8 trials of 100 000 UEs run 52 ms on 8 x 32 workgroups — the lean kernel, one XCD each —
+                //  against 78 ms on 8 x 16, 16 trials 78 ms on 16 x 16 against 96 ms on 16 x 8: scripts/r03_probe_g.py)
+                while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident && G * 2 <= std::max(1, minGroups / 16)) G *= 2;
                 // Uniform arrivals over 60 000 subframes (Beta.c:92-95): only nUE / 60 000 arrivals per subframe, a UE lives some
                 // tens of subframes, finished groups are skipped 32 at a time — the live band is a few groups and one workgroup
                 // steps through a subframe faster than a cluster exchanges (nUE = 100 000: 5.1 vs 6.2 us per subframe)
