@@ -625,6 +625,10 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
                 // Uniform arrivals over 60 000 subframes (Beta.c:92-95): only nUE / 60 000 arrivals per subframe, a UE lives some
                 // tens of subframes, finished groups are skipped 32 at a time — the live band is a few groups and one workgroup
                 // steps through a subframe faster than a cluster exchanges (nUE = 100 000: 5.1 vs 6.2 us per subframe)
+                // two workgroups per trial are not worth their exchange: 100 sweep trials run 151 / 242 ms (Beta.c / WithNOMA) on the batch kernel, one
+                // workgroup each, against 221 / 471 ms on 2-workgroup clusters, whose halves of a 100 000-UE trial also overflow the 512 event
+                // granules of a mailbox (32 of 100 trials rerun); from four workgroups per trial on, clusters win (scripts/r03_probe_mid.py)
+                if (G == 2 && mode == PRACH_RNG_PHILOX && e->opt_batch) G = 1;
                 bool light = mode == PRACH_RNG_PHILOX;
                 for (int k : idx) light = light && cfgs[k].uniform && cfgs[k].nUE <= 2000000;
                 if (light) G = 1;
