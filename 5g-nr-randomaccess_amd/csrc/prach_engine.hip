@@ -620,14 +620,14 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             if (G <= 0) {
                 G = 1;
                 // (the clusters of a call may fill the CUs: 8 trials of 100 000 UEs run 52 ms on 8 x 32 workgroups — the lean kernel, one XCD each —
-                //  against 78 ms on 8 x 16, 16 trials 78 ms on 16 x 16 against 96 ms on 16 x 8: scripts/r03_probe_g.py)
+                //  against 78 ms on 8 x 16, 16 trials 78 ms on 16 x 16 against 96 ms on 16 x 8: scripts/gpu_probe_cluster_sizes.py)
                 while (G * 2 <= 32 && (size_t)G * 2 * idx.size() <= resident && G * 2 <= std::max(1, minGroups / 16)) G *= 2;
                 // Uniform arrivals over 60 000 subframes (Beta.c:92-95): only nUE / 60 000 arrivals per subframe, a UE lives some
                 // tens of subframes, finished groups are skipped 32 at a time — the live band is a few groups and one workgroup
                 // steps through a subframe faster than a cluster exchanges (nUE = 100 000: 5.1 vs 6.2 us per subframe)
                 // two workgroups per trial are not worth their exchange: 100 sweep trials run 151 / 242 ms (Beta.c / WithNOMA) on the batch kernel, one
                 // workgroup each, against 221 / 471 ms on 2-workgroup clusters, whose halves of a 100 000-UE trial also overflow the 512 event
-                // granules of a mailbox (32 of 100 trials rerun); from four workgroups per trial on, clusters win (scripts/r03_probe_mid.py)
+                // granules of a mailbox (32 of 100 trials rerun); from four workgroups per trial on, clusters win (scripts/gpu_probe_mid_batches.py)
                 if (G == 2 && mode == PRACH_RNG_PHILOX && e->opt_batch) G = 1;
                 bool light = mode == PRACH_RNG_PHILOX;
                 for (int k : idx) light = light && cfgs[k].uniform && cfgs[k].nUE <= 2000000;
