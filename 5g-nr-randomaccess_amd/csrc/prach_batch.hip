@@ -10,7 +10,7 @@
 //         [15:0] tj   subframe from which the UE is matched by preambleCollision scans (its txTime)         0xFFFF: never
 //         [21:16] dur number of subframes it then contends with its RAR window open (Beta.c:245): matched in [tj, tj + dur)
 //         [29:24] preamble       [30] finished for good       [31] UL grant (set by the resolver with one atomicOr)
-//     A UE in steady contention is bumped every subframe (Beta.c:346,358) and counts one RAR-window subframe each time, so its
+//     (prach_ue_body.h: pw_make / pw_catch_up / pw_schedule).  A UE in steady contention is bumped every subframe (Beta.c:346,358) and counts one RAR-window subframe each time, so its
 //     whole trajectory until the window closes is known when it is scheduled: the walk only adds it to its bucket's histogram
 //     and keeps the bucket's lowest index (two LDS atomics), branch-free, and never writes.  A UE whose time has come
 //     (t == tj + dur: window expiry, Msg3, a deferred outcome) or that got a grant is an EVENT: its index goes to a queue.
@@ -48,9 +48,10 @@ constexpr int BSTG = 64 + 64 * BPF + 64; // per-wavefront stage: event UEs colle
 constexpr int BGROUPS = 8192; // 64-UE groups per trial at most (524 288 UEs): live-group lists of BGROUPS / NWB entries per wavefront
 // Workgroup shapes.  NWB wavefronts per workgroup: 16 (1024 threads, one workgroup = one trial per CU) or 8 (512 threads and an LDS
 // footprint under 80 KB, so that TWO workgroups = two independent trials share a CU: while one waits at a barrier or for its event
-// records, the other one issues).  Per-subframe capacities of the resolver's lists (more: the engine reruns the trial on trial_kernel):
+// records, the other one issues).  What is held in LDS per subframe (event list and event queue continue in global memory; the singleton
+// list BSC and the reset-cycle / crossing-bin lists RCCAP are capacities: beyond them the engine reruns the trial on trial_kernel):
 template <int NWB> struct BCap {
-    static constexpr int EV = NWB == 16 ? 4096 : 2048;  // gathered events
+    static constexpr int EV = NWB == 16 ? 4096 : 2048;  // events of a subframe held in LDS (more: global memory)
 #ifdef PRACH_QCAP
     static constexpr int Q = PRACH_QCAP;                  // (test build: nearly every subframe's queue continues in global memory)
 #else
