@@ -83,11 +83,11 @@ template <int NWB> struct BL {
     static constexpr int LCALL = FCALL + 8 * NPB;          // int [2][NPB]
     static constexpr int NLV = LCALL + 8 * NPB;            // int [NPB]
     static constexpr int FIE = NLV + 4 * NPB;              // int [NPB]
-    static constexpr int LIST = FIE + 4 * NPB;             // unsigned short [NWB][LCAP + 16]: per wavefront, the 64-UE groups it still has to look at
-    static constexpr int QUEUE = LIST + 2 * NWB * (C::LCAP + 16); // int [Q]
+    static constexpr int LIST = FIE + 4 * NPB;             // unsigned short [NWB][LCAP + 4 * BPF]: per wavefront, the 64-UE groups it still has to look at
+    static constexpr int QUEUE = LIST + 2 * NWB * (C::LCAP + 4 * BPF); // int [Q]
     static constexpr int STAGE = QUEUE + 4 * C::Q;         // int [NWB][BSTG + 64]: stage, then 64 per-lane dummy words (a lane without an event writes there)
     static constexpr int END = STAGE + 4 * NWB * (BSTG + 64);
-    static_assert(SIDX % 16 == 0 && LIST % 8 == 0 && (2 * (C::LCAP + 16)) % 8 == 0, "alignment");
+    static_assert(SIDX % 16 == 0 && LIST % 16 == 0 && (2 * (C::LCAP + 4 * BPF)) % 16 == 0, "alignment");
 };
 static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     auto ev_set = [&](const int k, const int a, const int b) { if (k < BEV) gev[k] = make_int2(a, b); else store_i2(&evov[k - BEV], a, b); };
     auto ev_kill = [&](const int k) { if (k < BEV) gev[k].y = 0; else evov[k - BEV].y = 0; };
     int *const queue = BI(bl::QUEUE);
-    unsigned short *const lst = reinterpret_cast<unsigned short *>(smem + bl::LIST) + w * (BLCAP + 16); // this wavefront's live groups
+    unsigned short *const lst = reinterpret_cast<unsigned short *>(smem + bl::LIST) + w * (BLCAP + 4 * BPF); // this wavefront's live groups
     int *const histx = BI(bl::HISTX), *const mlocx = BI(bl::MLOCX);
     int *const stage = BI(bl::STAGE) + w * (BSTG + 64);
 
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         BI(bl::FCALL)[tid] = INT_MAX; BI(bl::FCALL)[NPB + tid] = INT_MAX; BI(bl::LCALL)[tid] = -1; BI(bl::LCALL)[NPB + tid] = -1;
     }
     if (tid < 64) scal[tid] = 0;
-    if (lane < 16) lst[lane] = (unsigned short)totgroups; // empty list: padding entries only
+    if (lane < 4 * BPF) lst[lane] = (unsigned short)totgroups; // empty list: padding entries only
     __syncthreads();
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                     int g = g0 + ((w - g0) & (NWB - 1));
                     const int before = nlive;
                     for (; g < g1 && nlive < BLCAP; g += NWB) { if (lane == 0) lst[nlive] = (unsigned short)g; nlive++; } // (totgroups <= NWB * BLCAP: checked above)
-                    if (nlive != before && lane < 12) lst[nlive + lane] = (unsigned short)totgroups; // behind the last entry: the padding group (finished words)
+                    if (nlive != before && lane < 3 * BPF) lst[nlive + lane] = (unsigned short)totgroups; // behind the last entry: the padding group (finished words)
                 }
             }
             const bool retire = (t & 7) == (w & 7); // finished groups are looked for every 8th subframe (wave-uniform)
@@ -245,9 +245,10 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 }
             };
             // Software pipeline over the list, BPF groups per round: the entries of round r + 2 are read from LDS (one ds_read_b64, the same
-            // address in every lane), the pass words of round r + 1 are in flight, round r is worked on.  The list ends with >= 8 padding entries.
-            auto ld_ent = [&](const int k) -> uint2 { return *reinterpret_cast<const uint2 *>(lst + k); };
-            auto ent = [&](const uint2 E, const int d) -> unsigned { return d == 0 ? (E.x & 0xFFFFu) : d == 1 ? (E.x >> 16) : d == 2 ? (E.y & 0xFFFFu) : (E.y >> 16); };
+            // address in every lane), the pass words of round r + 1 are in flight, round r is worked on.  The list ends with >= 3 * BPF - 1 padding entries.
+            struct alignas(2 * BPF) Ent { unsigned v[BPF / 2]; }; // BPF 16-bit entries: one ds_read_b64 / b128
+            auto ld_ent = [&](const int k) -> Ent { return *reinterpret_cast<const Ent *>(lst + k); };
+            auto ent = [&](const Ent &E, const int d) -> unsigned { return (d & 1) ? (E.v[d >> 1] >> 16) : (E.v[d >> 1] & 0xFFFFu); };
             // (unconditional loads of mapped memory — the array is padded by one group of "finished" words.  A relaxed agent-scope load =
             //  global_load_dword ... sc1: served by L2, never by this CU's L1, because the grant bit is set by an L2 atomic.  NOT a
             //  non-temporal load: the words are read again every subframe, and marked streaming they lose their place in L2 / the
@@ -255,12 +256,12 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             auto ld_pw = [&](const unsigned g) -> unsigned { return __hip_atomic_load(pw + (g * 64u + (unsigned)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
             const int npad = (nlive + BPF - 1) & ~(BPF - 1);
             auto walk = [&](auto RETIRE) __attribute__((always_inline)) {
-                uint2 E0 = ld_ent(0), E1 = ld_ent(BPF);
+                Ent E0 = ld_ent(0), E1 = ld_ent(BPF);
                 unsigned W0[BPF];
 #pragma unroll
                 for (int d = 0; d < BPF; d++) W0[d] = ld_pw(ent(E0, d));
                 for (int k = 0; k < npad; k += BPF) {
-                    const uint2 E2 = ld_ent(k + 2 * BPF);
+                    const Ent E2 = ld_ent(k + 2 * BPF);
                     unsigned W1[BPF];
 #pragma unroll
                     for (int d = 0; d < BPF; d++) W1[d] = ld_pw(ent(E1, d));
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                     out += __popcll(km);
                 }
                 nlive = out;
-                if (lane < 12) lst[nlive + lane] = (unsigned short)totgroups;
+                if (lane < 3 * BPF) lst[nlive + lane] = (unsigned short)totgroups;
             }
             if (lane == 0 && npad) atomicAdd(&scal[B_VISITS], npad); // (reported, never read by the simulation)
         }

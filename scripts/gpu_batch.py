@@ -1,5 +1,6 @@
-"""Development probe: batched sweep throughput (BASELINE config 3 shape). Not a test."""
-import sys, time, os
+"""Development probe: batched sweep throughput (BASELINE config 3 shape). Not a test — but it prints a digest of every trial's
+result block, so that an experimental build whose output differs (and is therefore not measuring the same work) is seen at once."""
+import sys, time, os, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
@@ -17,7 +18,10 @@ res, _ = eng.run_trials(cfgs)
 wall = time.time() - t0
 tm = eng.timing()
 upd = sum(c.nUE * r.steps for c, r in zip(cfgs, res))
-print(f"trials={len(cfgs)} variant={variant} G={G} launches={tm.launches} wgs={tm.workgroups} kernel={tm.kernel_ms:.1f}ms wall={wall:.2f}s updates={upd:.3e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} algoGB/s={32*upd/(tm.kernel_ms*1e-3)/1e9:.0f} bad={sum(r.status!=0 for r in res)}")
+digest = 0
+for r in res:
+    digest = zlib.crc32(bytes(r), digest)
+print(f"digest={digest:08x} trials={len(cfgs)} variant={variant} G={G} launches={tm.launches} wgs={tm.workgroups} kernel={tm.kernel_ms:.1f}ms wall={wall:.2f}s updates={upd:.3e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} algoGB/s={32*upd/(tm.kernel_ms*1e-3)/1e9:.0f} bad={sum(r.status!=0 for r in res)}")
 # the kernel's OWN bytes.  batch_kernel (rec_mode 4): a visit reads one 4-byte pass word per lane; an event UE reads and writes one 32-byte
 # record, writes its pass word and passes through the queue (4 B in, 4 B out).  The general kernel's 8 + 4 byte form: 8 B per lane and visit, ~40 B per event.
 vis_b, ev_b = (256, 76) if tm.rec_mode == 4 else (512, 40)
