@@ -54,7 +54,7 @@ class PrachTiming(C.Structure):
                 ("launches", C.c_int32), ("workgroups", C.c_int32), ("updates", C.c_uint64),
                 ("cluster_size", C.c_int32), ("resident_limit", C.c_int32), ("fallback_trials", C.c_int32), ("spin_timeouts", C.c_int32),
                 ("rec_mode", C.c_int32), ("xcd_packed", C.c_int32), ("group_visits", C.c_uint64), ("event_ues", C.c_uint64),
-                ("trial_kernel_reruns", C.c_int32), ("reserved_", C.c_int32)]
+                ("trial_kernel_reruns", C.c_int32), ("noma_host_ues", C.c_int32)]
 
 
 class PrachError(RuntimeError):
@@ -105,6 +105,7 @@ def lib():
         L.prach_write_trial_files.argtypes = [C.POINTER(PrachCfg), C.POINTER(PrachResult), C.POINTER(PrachUeLog), C.c_double, C.c_char_p]
         L.prach_noma_activation_table.argtypes = [C.POINTER(PrachCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.prach_noma_activation_range.argtypes = [C.POINTER(PrachCfg), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.prach_noma_activation_table_device.argtypes = [C.c_void_p, C.POINTER(PrachCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.prach_format_noma_line.argtypes = [C.POINTER(PrachCfg), C.POINTER(PrachResult), C.c_char_p, C.c_size_t]
         L.prach_format_noma_line.restype = C.c_size_t
         L.prach_results_csv_accumulate.argtypes = [C.POINTER(C.c_double), C.c_char_p]
@@ -118,7 +119,8 @@ EXPORTS = ("prach_engine_create", "prach_engine_destroy", "prach_engine_set", "p
            "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_arrival_schedule", "prach_glibc_stream",
            "prach_strerror", "prach_format_logs", "prach_format_results", "prach_format_stdout",
            "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line",
-           "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream", "prach_noma_activation_range", "prach_noma_activation_stream")
+           "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream", "prach_noma_activation_range", "prach_noma_activation_stream",
+           "prach_noma_activation_table_device")
 
 
 def make_cfg(nUE, variant=VARIANT_BETA_C, uniform=0, rng_mode=RNG_GLIBC, seed=0, stream_offset=0, **kw) -> PrachCfg:
@@ -237,6 +239,20 @@ def noma_activation_table(cfg: PrachCfg):
     if rc != OK:
         raise PrachError(rc, "(prach_noma_activation_table)")
     return pre0, sec, gain, lgain, nd
+
+
+def noma_activation_table_device(engine, cfg: PrachCfg):
+    """The same table as the engine builds it on the GPU (Philox mode) + a per-UE flag: recomputed on the host (see include/prach.h)."""
+    import numpy as np
+    n = cfg.nUE
+    pre0, sec = np.empty(n, np.int32), np.empty(n, np.int32)
+    gain, lgain = np.empty(n, np.float64), np.empty(n, np.float64)
+    nd, flagged = np.empty(n, np.uint32), np.empty(n, np.uint8)
+    rc = lib().prach_noma_activation_table_device(engine._h, C.byref(cfg), pre0.ctypes.data, sec.ctypes.data, gain.ctypes.data, lgain.ctypes.data,
+                                                  nd.ctypes.data, flagged.ctypes.data)
+    if rc != OK:
+        raise PrachError(rc, "(prach_noma_activation_table_device)")
+    return pre0, sec, gain, lgain, nd, flagged
 
 
 def format_noma_line(cfg, res) -> bytes:

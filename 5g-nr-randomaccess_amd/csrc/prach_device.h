@@ -76,6 +76,8 @@ struct TrialDev {
     const int *n_pre0, *n_sector;
     const double *n_gain, *n_lgain;
     const unsigned *n_nd0;
+    float cell_radius;           // NOMA.c:56,168 (the UE drop of activeUE)
+    int n_devact;                // 1: the table was built on the device (noma_activation_kernel): the resolver checks its gain comparisons against the error band
     int flags;                   // PRACH_FLAG_* (include/prach.h)
     int *sector;                 // PRACH_FLAG_SECTOR_GRANTS: per UE, the sector drawn by activateUEs (WithNOMA:393-410); else null
     // batch kernel (prach_batch.hip) only
@@ -123,6 +125,12 @@ constexpr int CLUSTER_MAX_G = 64;
 size_t noma_kernel_lds_bytes(int nP);
 hipError_t launch_noma_kernel(const TrialDev *params, int ntrials, int G, int maxP, int xpack, hipStream_t stream);
 int noma_kernel_blocks_per_cu(int maxP);
+// activeUE (NOMA.c:131-192) for every UE of every trial of a Philox launch, on the device.  flags[0]: number of UEs whose result may differ
+// from the host libm's (a value within the error band of a rounding or comparison boundary); flags[2 + 2 q], flags[3 + 2 q]: trial, UE index
+// of the q-th (q < cap).  The engine recomputes those with prach_noma_activation_range before the simulation kernel starts.
+constexpr int NOMA_ACT_FLAG_CAP = 8192;
+constexpr int NOMA_AMBIGUOUS = 77; // DevResult::hard_error: a gain comparison of the resolver fell inside the error band (the trial is rerun with the host-built table)
+hipError_t launch_noma_activation(const TrialDev *params, int ntrials, int maxUE, unsigned *flags, hipStream_t stream);
 // NOMA_C in the reference's own rand() stream (prach_noma_glibc.hip): one trial, host-activated arrivals + one device step per access slot
 int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *hstream, unsigned long long len, prach_result *res, prach_ue_log *logs,
                          double *kernel_ms);

@@ -109,6 +109,7 @@ struct TrialG {
     const PRACH_G int *n_pre0, *n_sector;
     const PRACH_G double *n_gain, *n_lgain;
     const PRACH_G unsigned *n_nd0;
+    int n_devact;
     int flags;
     PRACH_G int *sector;
 
@@ -121,7 +122,7 @@ struct TrialG {
           timers((PRACH_G int *)d.timers), out((PRACH_G DevResult *)d.out), evw(d.evw), mbstride(d.mbstride), binshift(d.binshift),
           mbox((PRACH_G int *)d.mbox), cand((PRACH_G v2i_t *)d.cand), dense_pass(d.dense_pass), pipeline(d.pipeline),
           n_pre0((const PRACH_G int *)d.n_pre0), n_sector((const PRACH_G int *)d.n_sector), n_gain((const PRACH_G double *)d.n_gain),
-          n_lgain((const PRACH_G double *)d.n_lgain), n_nd0((const PRACH_G unsigned *)d.n_nd0), flags(d.flags), sector((PRACH_G int *)d.sector) {}
+          n_lgain((const PRACH_G double *)d.n_lgain), n_nd0((const PRACH_G unsigned *)d.n_nd0), n_devact(d.n_devact), flags(d.flags), sector((PRACH_G int *)d.sector) {}
 };
 
 // The hot record is read with a non-temporal 16-byte load (global_load_dwordx4 ... nt: served by L2, never

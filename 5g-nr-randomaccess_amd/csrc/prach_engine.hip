@@ -54,6 +54,10 @@ struct prach_engine {
     int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
     int64_t opt_batch = 1;         // 0: one-workgroup-per-trial Philox launches run on the general kernel instead of prach_batch.hip
     int64_t opt_batch_waves = 0;   // wavefronts per batch-kernel workgroup: 8 (512 threads, two trials per CU), 16 (one), 0 = chosen per launch
+    int64_t opt_noma_host_activation = 0; // 1: NOMA.c's activeUE table is built on the host (the reference's libm) instead of by noma_activation_kernel
+    int64_t opt_noma_ambiguity_test = 0;  // test hook: the resolver reports every gain sort as ambiguous (exercises the rerun with the host-built table)
+    bool force_host_act = false;   // (set for the rerun of trials whose device-built table left a gain comparison inside the error band)
+    int noma_flagged = 0, noma_ambiguous = 0; // last call: UEs recomputed on the host, trials rerun with the host-built table
     int num_cus = 256;
 };
 
@@ -78,6 +82,7 @@ struct TrialLayout {
 struct LaunchLayout {
     std::vector<TrialLayout> t;
     size_t staged_end = 0, zero_begin = 0, zero_end = 0, out0 = 0, end = 0;
+    size_t act_flags = 0; // NOMA.c: noma_activation_kernel's list of UEs for the host (in the zeroed region)
 };
 
 size_t mbox_bytes(const prach_cfg &c, int G, int &evw, int &mbstride) {
@@ -115,6 +120,7 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         const size_t mb = mbox_bytes(cfgs[idx[k]], G, L.t[k].evw, L.t[k].mbstride);
         L.t[k].mbox = mb ? take(mb) : 0;
     }
+    if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) L.act_flags = take(4 * (2 + 2 * (size_t)NOMA_ACT_FLAG_CAP));
     L.zero_end = o;
     for (int k = 0; k < m; k++) {
         const prach_cfg &c = cfgs[idx[k]];
@@ -241,6 +247,45 @@ static bool use_fast_kernel(const prach_engine *e, int lslots, int maxP) {
     return lslots > 0 && e->opt_fast && e->opt_pipeline && maxP <= lcluster_max_preambles() && lcluster_kernel_lds_bytes(lslots) <= CLUSTER_LDS_LIMIT;
 }
 
+// NOMA.c's activeUE table on the device: noma_activation_kernel for every UE of the launch, then the few UEs whose value sits within the
+// device math library's error band of a rounding / comparison boundary (~1e-6 of them) are recomputed with the host's libm
+// (prach_noma_activation_range) and patched in.  dparams: the launch's TrialDev blocks (device), tabs[k]: trial k's table arrays (device).
+struct ActTab { char *pre0, *sec, *gain, *lgain, *nd0; };
+static int noma_device_activation(prach_engine *e, const TrialDev *dparams, const prach_cfg *cfgs, const int *idx, int m, const std::vector<ActTab> &tabs,
+                                  unsigned *dflags, std::vector<std::pair<int, int>> *flagged) {
+    int maxUE = 0;
+    for (int k = 0; k < m; k++) maxUE = std::max(maxUE, cfgs[idx[k]].nUE);
+    HIPCHK(launch_noma_activation(dparams, m, maxUE, dflags, e->stream));
+    unsigned nflag = 0;
+    HIPCHK(hipMemcpyAsync(&nflag, dflags, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (nflag > (unsigned)NOMA_ACT_FLAG_CAP) {
+        std::fprintf(stderr, "[prach] noma_activation_kernel flagged %u UEs (more than its list holds)\n", nflag);
+        return PRACH_ERR_INTERNAL;
+    }
+    if (!nflag) return PRACH_OK;
+    std::vector<unsigned> fl(2 * (size_t)nflag);
+    HIPCHK(hipMemcpy(fl.data(), dflags + 2, 8 * (size_t)nflag, hipMemcpyDeviceToHost));
+    for (unsigned q = 0; q < nflag; q++) {
+        const int k = (int)fl[2 * q], i = (int)fl[2 * q + 1];
+        if (k < 0 || k >= m || i < 0 || i >= cfgs[idx[k]].nUE) return PRACH_ERR_INTERNAL;
+        int32_t pre0, sec;
+        double gn, lg;
+        uint32_t nd0;
+        const int arc = prach_noma_activation_range(&cfgs[idx[k]], i, i + 1, &pre0, &sec, &gn, &lg, &nd0);
+        if (arc != PRACH_OK) return arc;
+        const ActTab &T = tabs[k];
+        HIPCHK(hipMemcpy(T.pre0 + 4 * (size_t)i, &pre0, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(T.sec + 4 * (size_t)i, &sec, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(T.gain + 8 * (size_t)i, &gn, 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(T.lgain + 8 * (size_t)i, &lg, 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(T.nd0 + 4 * (size_t)i, &nd0, 4, hipMemcpyHostToDevice));
+        if (flagged) flagged->push_back({k, i});
+    }
+    e->noma_flagged += (int)nflag;
+    return PRACH_OK;
+}
+
 static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int m, prach_result *results,
                      prach_ue_log *const *ue_logs, int attempt, int G, double &kernel_ms, double &upload_ms) {
     const int rng_mode = cfgs[idx[0]].rng_mode;
@@ -258,6 +303,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         const prach_cfg &c = cfgs[idx[k]];
         batch = c.maxRarWindow <= batch_max_rar_window() && (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups();
     }
+    // NOMA.c's activeUE table: built by the device (noma_activation_kernel) unless the option or a rerun asks for the host's libm
+    const bool host_act = noma && (e->opt_noma_host_activation || e->force_host_act);
     const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G, batch);
     { int rc = ensure_arena(e, LL.end); if (rc != PRACH_OK) return rc; }
     { int rc = ensure_pinned(e, std::max(LL.staged_end, sizeof(DevResult) * (size_t)m)); if (rc != PRACH_OK) return rc; }
@@ -325,9 +372,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             d.n_pre0 = reinterpret_cast<const int *>(A + L.n_pre0); d.n_sector = reinterpret_cast<const int *>(A + L.n_sector);
             d.n_gain = reinterpret_cast<const double *>(A + L.n_gain); d.n_lgain = reinterpret_cast<const double *>(A + L.n_lgain);
             d.n_nd0 = reinterpret_cast<const unsigned *>(A + L.n_nd0);
+            d.cell_radius = c.cellRadius;
+            d.n_devact = host_act ? 0 : (e->opt_noma_ambiguity_test ? 2 : 1);
         }
     }
-    if (noma) {
+    if (noma && host_act) {
         // activeUE's per-UE attributes (NOMA.c:131-192: double-precision libm work, once per UE): built on the host with the
         // libm the reference links, UE ranges of all trials dealt to all host cores, then copied trial by trial
         const int nth = host_threads(e);
@@ -379,6 +428,12 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         for (int k = 0; k < m; k++)
             HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(A + LL.t[k].seeds), reinterpret_cast<int *>(A + LL.t[k].stream),
                                        (unsigned long long)LL.t[k].stream_len, e->stream));
+    if (noma && !host_act) { // activeUE for every UE of the launch, inside the timed region
+        std::vector<ActTab> tabs(m);
+        for (int k = 0; k < m; k++) tabs[k] = {A + LL.t[k].n_pre0, A + LL.t[k].n_sector, A + LL.t[k].n_gain, A + LL.t[k].n_lgain, A + LL.t[k].n_nd0};
+        int rc = noma_device_activation(e, reinterpret_cast<const TrialDev *>(A), cfgs, idx, m, tabs, reinterpret_cast<unsigned *>(A + LL.act_flags), nullptr);
+        if (rc != PRACH_OK) return rc;
+    }
     if (noma) {
         const int xpack = e->opt_xcd_pack && !e->pack_off && G > 1 && ((m + 7) / 8) * G <= e->num_cus / 8;
         e->last.xcd_packed = xpack;
@@ -447,6 +502,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         prach_result &r = results[idx[k]];
         std::memset(&r, 0, sizeof(r));
         r.status = (dr.hard_error && dr.status == PRACH_ERR_TIMEOUT) ? PRACH_ERR_INTERNAL : dr.status; // (a capacity overflow somewhere in the cluster is the cause, a peer's time-out its effect)
+        if (noma && dr.hard_error == NOMA_AMBIGUOUS && r.status == PRACH_OK) { r.status = PRACH_ERR_INTERNAL; e->noma_ambiguous++; } // (rerun with the host-built table: run_trials)
         r.time_exit = dr.time_exit;
         r.maxTime = prach_max_time(&c);
         r.nSuccessUE = dr.nSuccess;
@@ -529,6 +585,7 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
     HIPCHK(hipSetDevice(e->device));
     auto t0 = std::chrono::steady_clock::now();
     e->last = prach_timing{};
+    e->noma_flagged = e->noma_ambiguous = 0;
     double kernel_ms = 0, upload_ms = 0;
     // NOMA.c in the reference's OWN rand() stream: activeUE's rejection loops make every stream position data dependent and its libm
     // calls must be the reference's, so the arrivals are activated on the host between device steps (prach_noma_glibc.hip): one trial
@@ -572,9 +629,11 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             size_t nto = 0;
             for (int k : idx)
                 if (results[k].status == PRACH_ERR_TIMEOUT || results[k].status == PRACH_ERR_INTERNAL) { again.push_back(k); nto += results[k].status == PRACH_ERR_TIMEOUT; }
-            if (!again.empty() && G > 1) { // one workgroup per trial waits for nobody
-                note_fallback(e, "noma_kernel with one workgroup per trial", again.size(), nto, G);
+            if (!again.empty() && (G > 1 || e->noma_ambiguous > 0)) { // one workgroup per trial waits for nobody; the host-built table needs no error band
+                note_fallback(e, "noma_kernel with one workgroup per trial and the host-built activation table", again.size(), nto, G);
+                e->force_host_act = true;
                 rc = run_group(e, cfgs, again.data(), (int)again.size(), results, ue_logs, 0, 1, kernel_ms, upload_ms);
+                e->force_host_act = false;
                 if (rc != PRACH_OK) return rc;
             }
         }
@@ -698,6 +757,7 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
         if (results[k].status != PRACH_OK) worst = results[k].status;
     }
     e->last.kernel_ms = kernel_ms;
+    e->last.noma_host_ues = e->noma_flagged;
     e->last.upload_ms = upload_ms;
     e->last.updates = upd;
     e->last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -743,6 +803,8 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "batch") == 0) { e->opt_batch = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "noma_ambiguity_test") == 0) { e->opt_noma_ambiguity_test = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "noma_host_activation") == 0) { e->opt_noma_host_activation = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "batch_waves") == 0) { if (value != 0 && value != 8 && value != 16) return PRACH_ERR_ARG; e->opt_batch_waves = value; return PRACH_OK; }
     if (std::strcmp(key, "xcd_pack") == 0) { e->opt_xcd_pack = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
@@ -764,6 +826,49 @@ int prach_device_glibc_stream(prach_engine *e, uint32_t seed, uint64_t first, ui
         HIPCHK(hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
         return PRACH_OK;
     )
+}
+
+static int activation_table_device_impl(prach_engine *e, const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
+                                   uint32_t *ndraws, uint8_t *flagged) {
+    if (!e || !cfg || !preamble0 || !sector || !gain || !lgain || !ndraws) return PRACH_ERR_ARG;
+    { int v = prach_cfg_validate(cfg); if (v != PRACH_OK) return v; }
+    if (cfg->variant != PRACH_VARIANT_NOMA_C || cfg->rng_mode != PRACH_RNG_PHILOX) return PRACH_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t n = (size_t)cfg->nUE;
+    size_t o = align_up(sizeof(TrialDev), 256);
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t oflags = take(4 * (2 + 2 * (size_t)NOMA_ACT_FLAG_CAP)), opre = take(4 * n), osec = take(4 * n), ogain = take(8 * n), olg = take(8 * n), ond = take(4 * n);
+    { int rc = ensure_arena(e, o); if (rc != PRACH_OK) return rc; }
+    char *const A = e->arena;
+    TrialDev d;
+    std::memset(&d, 0, sizeof(d));
+    d.variant = cfg->variant; d.nUE = cfg->nUE; d.nP = cfg->nPreamble; d.seed_lo = (unsigned)cfg->seed; d.seed_hi = (unsigned)(cfg->seed >> 32);
+    d.cell_radius = cfg->cellRadius;
+    d.n_pre0 = reinterpret_cast<const int *>(A + opre); d.n_sector = reinterpret_cast<const int *>(A + osec);
+    d.n_gain = reinterpret_cast<const double *>(A + ogain); d.n_lgain = reinterpret_cast<const double *>(A + olg);
+    d.n_nd0 = reinterpret_cast<const unsigned *>(A + ond);
+    HIPCHK(hipMemcpy(A, &d, sizeof(d), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(A + oflags, 0, 8));
+    const int idx0 = 0;
+    std::vector<ActTab> tabs(1, ActTab{A + opre, A + osec, A + ogain, A + olg, A + ond});
+    std::vector<std::pair<int, int>> fl;
+    e->noma_flagged = 0;
+    { int rc = noma_device_activation(e, reinterpret_cast<const TrialDev *>(A), cfg, &idx0, 1, tabs, reinterpret_cast<unsigned *>(A + oflags), &fl); if (rc != PRACH_OK) return rc; }
+    HIPCHK(hipMemcpy(preamble0, A + opre, 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sector, A + osec, 4 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gain, A + ogain, 8 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lgain, A + olg, 8 * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ndraws, A + ond, 4 * n, hipMemcpyDeviceToHost));
+    if (flagged) {
+        std::memset(flagged, 0, n);
+        for (const auto &f : fl) flagged[f.second] = 1;
+    }
+    return PRACH_OK;
+}
+
+int prach_noma_activation_table_device(prach_engine *e, const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
+                                       uint32_t *ndraws, uint8_t *flagged) {
+    PRACH_GUARD(return activation_table_device_impl(e, cfg, preamble0, sector, gain, lgain, ndraws, flagged);)
 }
 
 int prach_last_timing(const prach_engine *e, prach_timing *out) {

@@ -56,6 +56,8 @@ int prach_cfg_validate(const prach_cfg *c) {
     if (c->flags & ~(PRACH_FLAG_SECTOR_GRANTS | PRACH_FLAG_NOMA_NONSECTOR)) return PRACH_ERR_ARG;
     if ((c->flags & PRACH_FLAG_SECTOR_GRANTS) && c->variant != PRACH_VARIANT_WITHNOMA_C) return PRACH_ERR_ARG; /* sectors exist in that program only */
     if ((c->flags & PRACH_FLAG_NOMA_NONSECTOR) && c->variant != PRACH_VARIANT_NOMA_C) return PRACH_ERR_ARG;
+    /* NOMA.c:167-172 redraws the UE's distance until it exceeds 35 m: with a cell radius of 35 m or less the reference itself never returns */
+    if (c->variant == PRACH_VARIANT_NOMA_C && !(c->cellRadius > 35.0f && c->cellRadius < 1e9f)) return PRACH_ERR_ARG;
     return PRACH_OK;
 }
 

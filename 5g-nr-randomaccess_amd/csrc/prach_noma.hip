@@ -4,8 +4,8 @@
 // Ownership of 64-UE groups is static and interleaved (group g -> workgroup g % G, wave (g / G) % 16), so a
 // UE's record never leaves its CU.  Work is organised per 5 ms ACCESS SLOT, not per subframe:
 //   (pass A of slot s+1 runs inside pass B of slot s: one sweep over the records per slot)
-//   pass A   activation of newly arrived UEs from the host-built activation table (activeUE, NOMA.c:131-192:
-//            first preamble, sector, Rayleigh channel gain — prach_noma_activation_table) and the
+//   pass A   activation of newly arrived UEs from the activation table (activeUE, NOMA.c:131-192: first preamble,
+//            sector, Rayleigh channel gain — built by noma_activation_kernel below, see there) and the
 //            transmitter gather of preambleSectorCollisionDetection (NOMA.c:206-212) as a 6 x nPreamble
 //            LDS histogram (count + lowest index per bin, LDS atomics);
 //   exchange (G > 1) every workgroup publishes its 6 x nPreamble bins as self-validating 8-byte granules
@@ -21,11 +21,16 @@
 //            (NOMA.c:499-546) for the slot's subframe AND the following accessTime-1 subframes in registers:
 //            a UE's record is loaded and stored once per slot.  Timers are stored as bases (NOMA.c:702-706
 //            costs no traffic).
-// Doubles are only compared / multiplied on the device (explicit _rn intrinsics, no contraction), never
-// produced by transcendental functions, so results are bit-identical to the reference's libm-based run.
+// In the simulation kernel doubles are only compared / multiplied (the library is built with -ffp-contract=off: HIP's _rn intrinsics are plain
+// operators, which the compiler would otherwise fuse into fma — one rounding where the reference has two).  The activation table's
+// cos / sin / log come from the device's math library, which is not the reference's libm to the last bit: every place where such a
+// value is rounded to float or compared is checked against an error band (noma_activation_kernel: flagged UEs are recomputed on the
+// host; the resolver: NOMA_AMBIGUOUS, the trial is rerun with the host-built table), so the RESULTS are the reference's bit for bit.
 #include "prach_device.h"
 #include "prach_device_fn.h"
 #include <limits.h>
+
+#pragma clang fp contract(off) // (a * b + c stays two roundings, as in the reference built for baseline x86-64)
 
 namespace prach {
 
@@ -48,7 +53,7 @@ struct NLds {
     double *slg; // [6*64] ln(gain)
     int *scal;   // [32]
 };
-enum { N_NSUCC = 0, N_STATUS, N_PTC, N_FC, N_MAXT, N_NSUCCTOT, N_MAXTTOT, N_PAIRD, N_SUMT = 8, N_ND = 10, N_SX = 12 };
+enum { N_NSUCC = 0, N_STATUS, N_PTC, N_FC, N_MAXT, N_NSUCCTOT, N_MAXTTOT, N_PAIRD, N_SUMT = 8, N_ND = 10, N_SX = 12, N_AMBIG = 13 };
 
 __device__ __forceinline__ NLds ncarve(char *smem, int nP) {
     NLds L;
@@ -88,6 +93,83 @@ __device__ __forceinline__ long long nwait(const PRACH_G long long *p, unsigned 
         g = nld(p);
     }
     return g;
+}
+
+// ---- activeUE on the device (NOMA.c:131-192) ----------------------------------------------------------------------------------
+// One thread per UE of every trial of the launch: the UE's own Philox counter gives its draws (preamble, angle, the radius rejection loop,
+// the Rayleigh-gain rejection loop), so UEs are independent.  Every +, x, /, sqrt and float <-> double conversion of the reference's
+// expression is an IEEE operation with one correctly rounded result (no contraction: -ffp-contract=off, and the pragma below) and therefore the
+// reference's; cos, sin and log are the device library's and may differ from the host libm's in the last bits, and pow(v, 2) is v x v
+// (the libm's pow is within 1 ulp of that).  What the simulation reads from this table is the preamble, the sector (float arithmetic
+// only), the draw count and the ORDER / log-difference of gains.  So a UE is FLAGGED, and recomputed on the host with the reference's libm
+// before the simulation starts, whenever a last-bits difference could change more than the last bits of its gain:
+//   * r cos(angle), r sin(angle) or sqrt(1 + env^2) lies within ACT_BAND double ulps of a float rounding boundary (the three values
+//     the reference rounds to float: NOMA.c:176-178,186) — 3 x 2 ACT_BAND / 2^29 = 7e-7 of the UEs;
+//   * a gain lies within 1e-12 (relative) of the rejection threshold 1e-7 (NOMA.c:185), is not finite, or a loop ran 4096 times.
+// The gains of unflagged UEs are within ~20 ulp of the reference's; the resolver's comparisons carry a band for that (NOMA_AMBIGUOUS).
+// tests/test_gpu_parity.py compares this table with prach_noma_activation_table (host libm) UE by UE.
+constexpr long long ACT_BAND = 64;
+
+__device__ __forceinline__ bool near_float_boundary(const double p) { // could (float)p differ from (float)p' for |p' - p| <= ACT_BAND ulps?
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(p);
+    long long d = (long long)(bits & ((1ull << 29) - 1ull)) - (1ll << 28); // the 29 bits a float drops; the rounding boundary is their midpoint
+    if (d < 0) d = -d;
+    return d <= ACT_BAND || !(fabs(p) > 1e-30 && fabs(p) < 1e30); // (outside the float's normal range the dropped bits are others: never happens here)
+}
+
+__global__ __launch_bounds__(256) void noma_activation_kernel(const TrialDev *__restrict__ params, const int ntrials, unsigned *__restrict__ flags) {
+    const int T = blockIdx.y;
+    if (T >= ntrials) return;
+    const TrialDev &P = params[T];
+    const int i = blockIdx.x * 256 + threadIdx.x, nUE = P.nUE;
+    if (i >= nUE) return;
+    unsigned k = 0;
+    bool flag = false;
+    auto draw = [&]() -> int { return philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k++, (unsigned)nUE, NOMA_VARIANT); };
+    const float pi = 3.14f; // NOMA.c:55
+    const int pre = draw() % P.nP; // NOMA.c:133
+    // (float)rand() / (float)(2147483647) * 2 * pi (NOMA.c:142): (float)2147483647 is 2^31, the division and the doubling are exact scalings
+    const float angle = __fmul_rn(__fmul_rn(__fmul_rn((float)draw(), 0x1p-31f), 2.0f), pi);
+    const double a = (double)angle, dpi = (double)pi;
+    int sec; // NOMA.c:146-163 (the constants are double products of the float pi; `angle >= pi` is the float comparison it is there)
+    if (a >= 0 && a < (1. / 3.) * dpi) sec = 0;
+    else if (a >= (1. / 3.) * dpi && a < (2. / 3.) * dpi) sec = 1;
+    else if (a >= (2. / 3.) * dpi && a < 3.14) sec = 2;
+    else if (angle >= pi && a < (4. / 3.) * dpi) sec = 3;
+    else if (a >= (4. / 3.) * dpi && a < (5. / 3.) * dpi) sec = 4;
+    else sec = 5;
+    float r;
+    for (int it = 0;; it++) { // NOMA.c:167-172
+        const float u = __fmul_rn((float)draw(), 0x1p-31f);
+        r = (float)__dmul_rn((double)P.cell_radius, __dsqrt_rn((double)u));
+        if ((double)r > 35.0) break;
+        if (it >= 4096) { flag = true; break; }
+    }
+    const double px = __dmul_rn((double)r, cos(a)), py = __dmul_rn((double)r, sin(a)); // NOMA.c:176-177
+    flag = flag || near_float_boundary(px) || near_float_boundary(py);
+    const float x = (float)px, y = (float)py;
+    const double env = __dsqrt_rn((double)__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y))); // NOMA.c:178 (float products, float sum)
+    const double pld = __dsqrt_rn(__dadd_rn(1.0, __dmul_rn(env, env)));                 // NOMA.c:186
+    flag = flag || near_float_boundary(pld);
+    const float pathloss = (float)pld;
+    double ch_g = 0;
+    for (int it = 0; ch_g < 1e-7; it++) { // NOMA.c:185-189
+        const double u = __ddiv_rn((double)draw(), 2147483647.0);
+        const double rayleigh = __dsqrt_rn(__dmul_rn(-2.0, log(u)));
+        const double q = __ddiv_rn(rayleigh, (double)pathloss);
+        ch_g = __dmul_rn(q, q);
+        if (fabs(__dsub_rn(ch_g, 1e-7)) <= 1e-19 || !(ch_g < 1e300)) flag = true;
+        if (it >= 4096) { flag = true; break; }
+    }
+    const_cast<int *>(P.n_pre0)[i] = pre;
+    const_cast<int *>(P.n_sector)[i] = sec;
+    const_cast<double *>(P.n_gain)[i] = ch_g;
+    const_cast<double *>(P.n_lgain)[i] = log(ch_g);
+    const_cast<unsigned *>(P.n_nd0)[i] = k;
+    if (flag) {
+        const unsigned q = atomicAdd(&flags[0], 1u);
+        if (q < (unsigned)NOMA_ACT_FLAG_CAP) { flags[2 + 2 * q] = (unsigned)T; flags[3 + 2 * q] = (unsigned)i; }
+    }
 }
 
 } // namespace
@@ -152,6 +234,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     // "one of the two" always decodes the weaker UE, without the second draw (NOMA.c:413-415 vs :287-290)
     const bool nonsector = (P.flags & PRACH_FLAG_NOMA_NONSECTOR) != 0;
     const int nsect = nonsector ? 1 : 6;
+    const bool devact = P.n_devact != 0;
 
     // pass A for one UE of the slot whose subframe is tA: activation of the newly arrived (activeUE, NOMA.c:131-140: everything
     // else comes from the activation table) and the transmitter gather (NOMA.c:207: RA==0, txTime==time+1, msg2==0,
@@ -260,9 +343,15 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     int uidx = -1;
                     double ug = 0, ulg = 0;
                     int rank = 0;
+                    bool ambiguous = false;
                     if (lane < count) {
                         uidx = L.sidx[sct * 64 + lane]; ug = L.sg[sct * 64 + lane]; ulg = L.slg[sct * 64 + lane];
-                        for (int j = 0; j < count; j++) { const double gj = L.sg[sct * 64 + j]; rank += (gj < ug || (gj == ug && j < lane)) ? 1 : 0; }
+                        for (int j = 0; j < count; j++) {
+                            const double gj = L.sg[sct * 64 + j];
+                            rank += (gj < ug || (gj == ug && j < lane)) ? 1 : 0;
+                            // device-built table: two gains closer than the error band of the device's libm (~90 ulp) could be ordered the other way by the reference's
+                            if (devact && j != lane && (fabs(__dsub_rn(gj, ug)) <= 1e-14 * fmax(gj, ug) || P.n_devact == 2)) ambiguous = true; // (2: test hook, every sort counts as ambiguous)
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (lane < count) { L.sidx[sct * 64 + rank] = uidx; L.slg[sct * 64 + rank] = ulg; }
@@ -278,6 +367,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         const double lgi = __shfl(clg, i);
                         const double diff = __dsub_rn(__dmul_rn(10.0, clg), __dmul_rn(10.0, lgi)); // 10*log(high) - 10*log(low)
                         const bool cond = lane > 0 && lane != i && lane < count && ((valid >> lane) & 1ull) && diff > 15.0;
+                        if (devact && lane < count && fabs(__dsub_rn(diff, 15.0)) < 1e-9) ambiguous = true; // (|error| of 10 ln g1 - 10 ln g2 < 1e-12)
                         const unsigned long long mj = __ballot(cond);
                         if (!mj) continue;
                         const int j = __ffsll((long long)mj) - 1;
@@ -306,6 +396,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     }
                     if (grantme && ((cidx >> 6) % G) == b) grant_rec(&P.rec[cidx]);
                     if (b == 0 && lane == 0 && npd) atomicAdd(&L.scal[N_PAIRD], npd);
+                    if (__any(ambiguous) && lane == 0) L.scal[N_AMBIG] = 1;
                 }
             }
         }
@@ -471,6 +562,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
         gadd(&o->nSuccess, L.scal[N_NSUCC]);
         gadd(&o->finalSuccess, L.scal[N_NSUCC]);
         if (status != PRACH_OK) gmin(&o->status, status);
+        if (L.scal[N_AMBIG]) o->hard_error = NOMA_AMBIGUOUS; // (every workgroup resolves identically: they all store the same value)
         gmax(&o->dbg[0], (unsigned long long)(L.scal[N_MAXT] + 1)); // latest success subframe + 1 (host: exit time when all succeeded)
         if (b == 0) {
             o->time_exit = time_exit;
@@ -496,6 +588,13 @@ int noma_kernel_blocks_per_cu(int maxP) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&noma_kernel), WG_THREADS, lds) != hipSuccess || nb < 1) return 1;
     return nb;
+}
+
+hipError_t launch_noma_activation(const TrialDev *params, int ntrials, int maxUE, unsigned *flags, hipStream_t stream) {
+    if (ntrials <= 0 || maxUE <= 0) return hipSuccess;
+    if (ntrials > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(noma_activation_kernel, dim3((unsigned)((maxUE + 255) / 256), (unsigned)ntrials), dim3(256), 0, stream, params, ntrials, flags);
+    return hipGetLastError();
 }
 
 } // namespace prach

@@ -14,6 +14,8 @@
 #include "prach_device.h"
 #include "prach_device_fn.h"
 
+#pragma clang fp contract(off) // (a * b + c stays two roundings, as in the reference built for baseline x86-64)
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>

@@ -126,7 +126,8 @@ typedef struct prach_timing {
                                 the bytes it really moves (batch_kernel: a visit reads one 4-byte pass word per lane, an event reads and
                                 writes one 32-byte record and one pass word) */
     int32_t trial_kernel_reruns; /* of fallback_trials: trials that were (also) rerun on the one-workgroup, index-ordered trial_kernel */
-    int32_t reserved_;
+    int32_t noma_host_ues;       /* NOMA_C, Philox: UEs of the device-built activeUE table that the host recomputed with its libm (a value inside the
+                                    device math library's error band of a rounding / comparison boundary: ~1e-6 of the UEs) */
 } prach_timing;
 
 typedef struct prach_engine prach_engine;
@@ -172,9 +173,11 @@ const char *prach_strerror(int status);
 
 /* NOMA.c variant (PRACH_VARIANT_NOMA_C): per-UE attributes fixed at activation (activeUE, NOMA.c:131-192):
  * first preamble, sector, Rayleigh channel gain and its natural log (the pairing test of NOMA.c:276 uses
- * 10*log(high)-10*log(low)), and the number of draws the activation consumed.  The double-precision
- * libm work (cos, sin, log, pow) runs ONCE per UE here on the host, with the same libm the reference links,
- * so the device-side sort / pairing is bit-identical to the reference; the per-subframe loop is on the GPU.
+ * 10*log(high)-10*log(low)), and the number of draws the activation consumed.  This is the HOST form, with the libm the
+ * reference links (cos, sin, log, pow).  The engine builds the table on the DEVICE (prach_noma_activation_table_device below is that
+ * kernel on its own) and calls the host form only for the UEs the kernel flags: wherever a last-bits difference between the device's
+ * math library and the host's could change a float rounding, the rejection test or the draw count.  Engine option
+ * "noma_host_activation" = 1 builds the whole table with the functions here instead (the round-1/2 behaviour).
  * This table form is the Philox mode's (draw k of UE i is independent of every other UE).  In glibc mode the rejection loops make
  * every stream position data dependent: there the engine activates arrivals one by one with prach_noma_activation_stream below. */
 int prach_noma_activation_table(const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
@@ -182,6 +185,11 @@ int prach_noma_activation_table(const prach_cfg *cfg, int32_t *preamble0, int32_
 /* the same for the UEs [lo, hi) only (outputs indexed from lo): ranges are independent, the engine builds them on all host cores */
 int prach_noma_activation_range(const prach_cfg *cfg, int lo, int hi, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
                                 uint32_t *ndraws);
+/* The device-built table as the engine uses it (Philox mode), copied back: preamble0 / sector / ndraws of every UE equal the host form's;
+ * gain / lgain of an unflagged UE are within a few ulp of it (never read except through comparisons that carry an error band), those of a
+ * flagged UE (flagged[i] != 0; nullable) are the host form's, recomputed by this call.  For tests and diagnosis. */
+int prach_noma_activation_table_device(prach_engine *, const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
+                                       uint32_t *ndraws, uint8_t *flagged);
 /* activeUE for ONE UE in the reference's own rand() stream (glibc mode of the NOMA_C variant): draws stream[*pos...] in the reference's
  * order, *pos advances; PRACH_ERR_STREAM when the window of `avail` values is exhausted */
 int prach_noma_activation_stream(const prach_cfg *cfg, const int32_t *stream, uint64_t *pos, uint64_t avail, int32_t *preamble0, int32_t *sector,

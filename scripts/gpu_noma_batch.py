@@ -24,4 +24,4 @@ tm = eng.timing()
 upd = sum(c.nUE * r.steps for c, r in zip(cfgs, res))
 slots = sum(c.nUE * ((r.steps + 4) // 5) for c, r in zip(cfgs, res))
 print(f"mode={mode} trials={len(cfgs)} G={tm.cluster_size} launches={tm.launches} wgs={tm.workgroups} kernel={tm.kernel_ms:.2f}ms upload={tm.upload_ms:.2f}ms wall={wall*1e3:.1f}ms "
-      f"updates={upd:.4e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} wall_upd/s={upd/wall:.3e} ue_slots={slots:.4e} bad={sum(r.status != 0 for r in res)} fallback={tm.fallback_trials}")
+      f"updates={upd:.4e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} wall_upd/s={upd/wall:.3e} ue_slots={slots:.4e} bad={sum(r.status != 0 for r in res)} fallback={tm.fallback_trials} host_recomputed_ues={tm.noma_host_ues}")

@@ -30,7 +30,7 @@ def main():
     for f in FILES:
         with tempfile.TemporaryDirectory() as d:
             asm = os.path.join(d, "k.s")
-            p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+            p = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-ffp-contract=off", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
                                 os.path.join(SRC, f), "-o", asm], capture_output=True, text=True)
             if p.returncode:
                 sys.exit(p.stderr[-2000:])

@@ -188,3 +188,12 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600,
                        env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
     assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+
+
+def test_noma_cell_radius_must_exceed_the_redraw_threshold(pkg):
+    """NOMA.c:167-172 redraws a UE's distance until it exceeds 35 m: a smaller cell never terminates in the reference; the library refuses it."""
+    ok = pkg.make_cfg(100, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, cellRadius=36.0)
+    bad = pkg.make_cfg(100, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, cellRadius=35.0)
+    assert pkg.lib().prach_cfg_validate(ok) == pkg.OK and pkg.lib().prach_cfg_validate(bad) == -1  # PRACH_ERR_ARG
+    beta = pkg.make_cfg(100, cellRadius=1.0)  # (the other programs parse the flag and never read it: WithNOMA:80-82)
+    assert pkg.lib().prach_cfg_validate(beta) == pkg.OK

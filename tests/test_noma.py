@@ -116,6 +116,60 @@ def test_gpu_noma_full_size_and_statistics(pkg, ob, engine):
 
 
 @pytest.mark.gpu
+def test_gpu_noma_activation_table_device_vs_host(pkg, engine):
+    """activeUE on the device (noma_activation_kernel, NOMA.c:131-192) against the host form built with the reference's libm:
+    preamble, sector and draw count of EVERY UE identical; the gain of a UE the kernel did not flag within 32 ulp of the host's (the
+    resolver's comparison band is ~90 ulp), of a flagged UE the host's bits (recomputed); few UEs flagged (the expected rate is
+    3 x 128 / 2^29 = 7e-7: float rounding boundaries of x, y and the path loss)."""
+    nflag = ntot = 0
+    worst = 0
+    for nUE, seed, kw in ((1000000, 0, {}), (1000000, 123456789, {}), (300000, 7, dict(cellRadius=60.0, nPreamble=7)), (1000, 1, dict(cellRadius=1500.0))):
+        cfg = pkg.make_cfg(nUE, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=seed, **kw)
+        hp, hs, hg, hl, hn = pkg.noma_activation_table(cfg)
+        dp, ds, dg, dl, dn, fl = pkg.noma_activation_table_device(engine, cfg)
+        assert (hp == dp).all() and (hs == ds).all() and (hn == dn).all(), (nUE, seed)
+        f = fl != 0
+        assert (hg[f] == dg[f]).all() and (hl[f] == dl[f]).all()
+        ulp = np.abs(hg.view(np.int64) - dg.view(np.int64))  # (same sign, finite: the distance in representable doubles)
+        assert np.isfinite(hg).all() and (hg >= 1e-7).all()
+        worst = max(worst, int(ulp[~f].max()))
+        assert np.abs(hl - dl)[~f].max() < 1e-13
+        nflag += int(f.sum()); ntot += nUE
+    assert worst <= 32, worst
+    assert nflag <= 40, (nflag, ntot)
+    print(f"device activation table: {ntot} UEs, {nflag} recomputed on the host, largest gain difference of the others {worst} ulp")
+
+
+@pytest.mark.gpu
+def test_gpu_noma_host_activation_option_and_ambiguity_rerun(pkg, ob, engine, capfd):
+    """Same results whichever side builds the table; and the resolver's 'a gain comparison fell inside the error band' exit (forced by
+    the test hook for every sort) reruns the trial with the host-built table, visibly, and still matches the oracle."""
+    cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=s) for n, s in ((20000, 3), (3000, 4))]
+    res_d, logs_d = engine.run_trials(cfgs, want_logs=True)
+    assert engine.timing().fallback_trials == 0
+    engine.set("noma_host_activation", 1)
+    try:
+        res_h, logs_h = engine.run_trials(cfgs, want_logs=True)
+        assert engine.timing().noma_host_ues == 0
+    finally:
+        engine.set("noma_host_activation", 0)
+    engine.set("noma_ambiguity_test", 1)
+    try:
+        capfd.readouterr()
+        res_a, logs_a = engine.run_trials(cfgs, want_logs=True)
+        tm = engine.timing()
+        assert tm.fallback_trials >= 1 and "host-built activation table" in capfd.readouterr().err
+    finally:
+        engine.set("noma_ambiguity_test", 0)
+    for k, cfg in enumerate(cfgs):
+        ores, oues = ob.noma_run_trial(ob.make_noma_cfg(cfg.nUE), ob.Rng(ob.RNG_PHILOX, cfg.seed))
+        b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
+        for res, logs in ((res_d[k], logs_d[k]), (res_h[k], logs_h[k]), (res_a[k], logs_a[k])):
+            assert (res.status, res.nSuccessUE, res.sumTimer, res.preambleTxCount, res.draws) == (0, ores.nSuccessUE, ores.delay, ores.nTxP, ores.draws)
+            assert (np.frombuffer(logs, dtype=np.int32).reshape(-1, 16) == b).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("G", [1, 4, 32])
 def test_gpu_noma_cluster_sizes(pkg, ob, engine, G):
     """The NOMA kernel with G workgroups per trial (one granule exchange per 5 ms slot) == the oracle for every G;
