@@ -63,7 +63,7 @@ template <int NWB> struct BCap {
 constexpr int EVB_CALLER = UEV_CALLER, EVB_RESETCAND = UEV_RESETCAND, EVB_RJOIN = UEV_RJOIN, EVB_LEAVER = 4;
 
 enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_SPARE, B_NEV, B_NCAND, B_QN, B_NCROSS, B_PTC, B_FC, B_SUMT = 16, B_ND = 18,
-       B_VISITS = 20, B_EVENTS = 21 };
+       B_VISITS = 20, B_EVENTS = 21, B_SGC = 24 /* [24, 30): sectorGrants[6], WithNOMA:260 (PRACH_FLAG_SECTOR_GRANTS) */ };
 
 // ---- LDS layout: byte offsets, all compile-time ------------------------------------------------------------------------------------
 template <int NWB> struct BL {
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nUE = PD->nUE, nP = PD->nP, aT = PD->aT, stop = PD->stop, nGrantUL = PD->nGrantUL, binshift = PD->binshift;
     const int variant = PD->variant;
+    const bool sectors = (PD->flags & PRACH_FLAG_SECTOR_GRANTS) != 0;
     const unsigned seed_lo = PD->seed_lo, seed_hi = PD->seed_hi;
     UeK K;
     K.maxRar = PD->maxRarWindow; K.maxMsg2 = PD->maxMsg2; K.aT = aT; K.withnoma = variant == PRACH_VARIANT_WITHNOMA_C;
@@ -178,7 +179,10 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     for (int t = 0; t < stop && status == PRACH_OK; t++) {
         steps++;
         tlast = t;
-        if (t % 5 == 0) grantCheck = 0; // Beta.c:112 (hard-coded 5)
+        if (t % 5 == 0) { // Beta.c:112 (hard-coded 5); WithNOMA:268-274
+            grantCheck = 0;
+            if (sectors && tid < 6) scal[B_SGC + tid] = 0; // (barriers follow before the grant phase reads them)
+        }
         const int prevAC = activeCheck;
         if (t % aT == 0 && activeCheck != nUE) activeCheck = sched[t / aT]; // Beta.c:121-134
         const int parity = t & 1;
@@ -515,7 +519,78 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         if (ns > BSC) { status = PRACH_ERR_INTERNAL; why = 3; time_exit = t; break; }
         const int Gr = max(0, nGrantUL - 1 - grantCheck); // Beta.c:336-347
         auto grant = [&](const int my) { __hip_atomic_fetch_or(pw + my, PW_GRANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // ONE fire-and-forget L2 atomic
-        if (Gr > 0 && ns > 0 && ns <= 64) {
+        if (sectors) {
+            // the dormant per-sector grant test (WithNOMA:626-637 with the call of :312): every 60-degree sector has its own budget of the 5 ms
+            // window, grantCheck[sector] counts that sector's singleton callers.  A caller's sector is a function of its first activation draw
+            // (Philox: the UE's own counter, draw 0), recomputed here.  Up to one wavefront of singleton callers: ranked through v_readlane.
+            if (ns > 0 && ns <= 64) {
+                if (tid < 64) {
+                    const int nsu = __builtin_amdgcn_readfirstlane(ns);
+                    const bool have = tid < nsu;
+                    const int my = have ? BI(bl::SIDX)[tid] : INT_MAX;
+                    const int sec = have ? sector_of_draw(philox_draw31(seed_lo, seed_hi, (unsigned)my, 0u, (unsigned)nUE, (unsigned)variant)) : 7;
+                    int rank = 0;
+                    for (int s_ = 0; s_ < nsu; s_++) rank += (__builtin_amdgcn_readlane(my, s_) < my && __builtin_amdgcn_readlane(sec, s_) == sec) ? 1 : 0;
+                    if (have && rank < nGrantUL - 1 - scal[B_SGC + sec]) grant(my);
+                    int mine = 0;
+#pragma unroll
+                    for (int s_ = 0; s_ < 6; s_++) { const int c = __popcll(__ballot(sec == s_)); mine = tid == s_ ? c : mine; }
+                    if (tid < 6) scal[B_SGC + tid] += mine; // (read above by this wavefront only, in program order)
+                }
+            } else if (ns > 0) {
+                // more than a wavefront of singleton callers (several per preamble: callers whose bucket's other members have left, Beta.c:321-330): the
+                // bin selection below with the key (sector, index): sector s owns the bins [s SB, (s + 1) SB), eight times coarser in the index
+                int *const bins = BI(bl::BINS), *const sidx = BI(bl::SIDX), *const rcl = BI(bl::RCL), *const wtot = BI(bl::WTOT);
+                constexpr int PER = BGB / TB, SB = BGB / 8;
+                const int shift = binshift + 3;
+#pragma unroll
+                for (int u_ = 0; u_ < PER; u_++) bins[tid * PER + u_] = 0;
+                if (tid == 0) scal[B_NCROSS] = 0;
+                __syncthreads();
+                for (int j = tid; j < ns; j += TB) {
+                    const int my = sidx[j];
+                    const int sec = sector_of_draw(philox_draw31(seed_lo, seed_hi, (unsigned)my, 0u, (unsigned)nUE, (unsigned)variant));
+                    sidx[j] = my | (sec << 24); // (UE indices have 20 bits)
+                    atomicAdd(&bins[sec * SB + (my >> shift)], 1);
+                }
+                __syncthreads();
+                {
+                    int c[PER], sum = 0;
+#pragma unroll
+                    for (int u_ = 0; u_ < PER; u_++) { c[u_] = bins[tid * PER + u_]; sum += c[u_]; }
+                    const int x = wave_scan_incl(sum);
+                    if (lane == 63) wtot[w] = x;
+                    __syncthreads();
+                    int run = x - sum;
+                    for (int k = 0; k < w; k++) run += wtot[k];
+#pragma unroll
+                    for (int u_ = 0; u_ < PER; u_++) { bins[tid * PER + u_] = run; run += c[u_]; } // exclusive prefix
+                }
+                __syncthreads();
+                for (int j = tid; j < ns; j += TB) {
+                    const int e_ = sidx[j], my = e_ & 0xFFFFFF, sec = e_ >> 24;
+                    const int bin = sec * SB + (my >> shift);
+                    const int Gs = nGrantUL - 1 - scal[B_SGC + sec];
+                    const int before = bins[bin] - bins[sec * SB]; // singleton callers of this sector in lower bins
+                    if (before >= Gs) continue;
+                    const int cnt = (bin + 1 < BGB ? bins[bin + 1] : ns) - bins[bin];
+                    if (before + cnt <= Gs) grant(my);
+                    else { const int s_ = atomicAdd(&scal[B_NCROSS], 1); if (s_ < RCCAP) rcl[s_] = e_; }
+                }
+                __syncthreads();
+                const int ncross = scal[B_NCROSS];
+                if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; why = 4; time_exit = t; break; }
+                if (tid < ncross) {
+                    const int e_ = rcl[tid], my = e_ & 0xFFFFFF, sec = e_ >> 24;
+                    const int bin = sec * SB + (my >> shift);
+                    int rank = bins[bin] - bins[sec * SB];
+                    for (int m = 0; m < ncross; m++) { const int o = rcl[m]; rank += ((o >> 24) == sec && ((o & 0xFFFFFF) >> shift) == (my >> shift) && (o & 0xFFFFFF) < my) ? 1 : 0; }
+                    if (rank < nGrantUL - 1 - scal[B_SGC + sec]) grant(my);
+                }
+                __syncthreads(); // (the budgets were read above)
+                if (tid < 6) scal[B_SGC + tid] += bins[(tid + 1) * SB] - bins[tid * SB];
+            }
+        } else if (Gr > 0 && ns > 0 && ns <= 64) {
             if (tid < 64) { // up to one wavefront of singleton callers: every lane ranks its own index against the others through v_readlane
                 const int nsu = __builtin_amdgcn_readfirstlane(ns);
                 const int my = tid < nsu ? BI(bl::SIDX)[tid] : INT_MAX;
@@ -568,7 +643,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         }
         grantCheck += ns;
         BSTAMP(11); // grants
-        if (Gr > 0 && ns > 0) __syncthreads(); // S6: the grants are in the pass words before the next walk reads them
+        if ((Gr > 0 || sectors) && ns > 0) __syncthreads(); // S6: the grants are in the pass words before the next walk reads them
         BSTAMP(12);
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }

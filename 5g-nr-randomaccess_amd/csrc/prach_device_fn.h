@@ -46,6 +46,19 @@ __device__ __forceinline__ int philox_draw31(unsigned k0, unsigned k1, unsigned 
     return (int)(c0 >> 1);
 }
 
+// activateUEs (WithNOMA:393-410): theta from the first of the two activation draws fixes the UE's 60-degree sector (float arithmetic and
+// comparisons with double constants only: the reference's value on any IEEE machine)
+__device__ __forceinline__ int sector_of_draw(const int d) {
+    const float pi = 3.14f;
+    const float theta = (float)d / (float)2147483647 * 2 * pi;
+    if (theta >= 0 && theta < ((1. / 3.) * pi)) return 0;
+    if (theta >= ((1. / 3.) * pi) && theta < ((2. / 3.) * pi)) return 1;
+    if (theta >= ((2. / 3.) * pi) && theta < 3.14) return 2;
+    if (theta >= pi && theta < ((4. / 3.) * pi)) return 3;
+    if (theta >= ((4. / 3.) * pi) && theta < ((5. / 3.) * pi)) return 4;
+    return 5;
+}
+
 __device__ __forceinline__ unsigned long long lanemask_le(int lane) {
     return lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
 }

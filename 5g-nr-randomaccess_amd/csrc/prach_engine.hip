@@ -247,6 +247,13 @@ static bool use_fast_kernel(const prach_engine *e, int lslots, int maxP) {
     return lslots > 0 && e->opt_fast && e->opt_pipeline && maxP <= lcluster_max_preambles() && lcluster_kernel_lds_bytes(lslots) <= CLUSTER_LDS_LIMIT;
 }
 
+// one workgroup per trial, Philox: can prach::batch_kernel (prach_batch.hip) run this trial?
+static bool batch_eligible(const prach_engine *e, const prach_cfg &c) {
+    if (c.variant == PRACH_VARIANT_NOMA_C || c.rng_mode != PRACH_RNG_PHILOX || !e->opt_batch || e->opt_dense || e->opt_wide_records) return false;
+    return c.nPreamble <= batch_max_preambles() && c.maxRarWindow <= batch_max_rar_window() &&
+           (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups();
+}
+
 // NOMA.c's activeUE table on the device: noma_activation_kernel for every UE of the launch, then the few UEs whose value sits within the
 // device math library's error band of a rounding / comparison boundary (~1e-6 of them) are recomputed with the host's libm
 // (prach_noma_activation_range) and patched in.  dparams: the launch's TrialDev blocks (device), tabs[k]: trial k's table arrays (device).
@@ -298,11 +305,10 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (c.nPreamble > maxP) maxP = c.nPreamble;
     }
     // one workgroup per trial, Philox: the batch kernel (prach_batch.hip), within its limits
-    bool batch = G == 1 && !noma && rng_mode == PRACH_RNG_PHILOX && e->opt_batch && !e->opt_dense && !e->opt_wide_records && maxP <= batch_max_preambles();
-    for (int k = 0; k < m && batch; k++) {
-        const prach_cfg &c = cfgs[idx[k]];
-        batch = c.maxRarWindow <= batch_max_rar_window() && (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups();
-    }
+    bool batch = G == 1;
+    for (int k = 0; k < m && batch; k++) batch = batch_eligible(e, cfgs[idx[k]]);
+    for (int k = 0; k < m; k++) // the dormant per-sector grant path exists in trial_kernel (G == 0) and in the batch kernel only
+        if ((cfgs[idx[k]].flags & PRACH_FLAG_SECTOR_GRANTS) && G > 0 && !batch) return PRACH_ERR_INTERNAL;
     // NOMA.c's activeUE table: built by the device (noma_activation_kernel) unless the option or a rerun asks for the host's libm
     const bool host_act = noma && (e->opt_noma_host_activation || e->force_host_act);
     const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G, batch);
@@ -653,13 +659,22 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
         // cluster kernels' 20-bit granule fields / group tables — they leave the others on the cluster kernels
         std::vector<int> solo;
         {
-            std::vector<int> rest;
+            std::vector<int> rest, sect;
             for (int k : idx) {
-                const bool only_trial_kernel = (cfgs[k].flags & PRACH_FLAG_SECTOR_GRANTS) || cfgs[k].nUE >= (1 << 20) - 1 ||
-                                               (mode == PRACH_RNG_GLIBC && cfgs[k].nUE > CLUSTER_GLIBC_MAX_UE);
-                (only_trial_kernel ? solo : rest).push_back(k);
+                const bool sector = (cfgs[k].flags & PRACH_FLAG_SECTOR_GRANTS) != 0;
+                const bool only_trial_kernel = sector || cfgs[k].nUE >= (1 << 20) - 1 || (mode == PRACH_RNG_GLIBC && cfgs[k].nUE > CLUSTER_GLIBC_MAX_UE);
+                (sector && !e->opt_legacy && batch_eligible(e, cfgs[k]) ? sect : only_trial_kernel ? solo : rest).push_back(k);
             }
             idx.swap(rest);
+            if (!sect.empty()) {
+                // the per-sector grant path in Philox mode: the batch kernel keeps the six budgets (one launch for these trials, one workgroup each;
+                // what exceeds a capacity of its resolver goes on to trial_kernel like any other trial)
+                int rc = run_group(e, cfgs, sect.data(), (int)sect.size(), results, ue_logs, 0, 1, kernel_ms, upload_ms);
+                if (rc != PRACH_OK) return rc;
+                size_t nbad = 0;
+                for (int k : sect) if (results[k].status != PRACH_OK) { solo.push_back(k); nbad++; }
+                if (nbad) { note_fallback(e, "trial_kernel (one workgroup per trial, no per-subframe capacity)", nbad, 0, 1); e->last.trial_kernel_reruns += (int32_t)nbad; }
+            }
         }
         const bool cluster_ok = !e->opt_legacy && !idx.empty();
         int maxP = 1;

@@ -431,16 +431,7 @@ __global__ __launch_bounds__(WG_THREADS) void trial_kernel(const TrialDev *__res
                 const unsigned long long so = base + 2ull * (unsigned long long)(i - prevAC);
                 const int d = GLIBC ? P.stream[so < P.stream_len ? so : 0ull]
                                     : philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, 0u, (unsigned)nUE, (unsigned)P.variant);
-                const float pi = 3.14f;
-                const float theta = (float)d / (float)2147483647 * 2 * pi;
-                int sec;
-                if (theta >= 0 && theta < ((1. / 3.) * pi)) sec = 0;
-                else if (theta >= ((1. / 3.) * pi) && theta < ((2. / 3.) * pi)) sec = 1;
-                else if (theta >= ((2. / 3.) * pi) && theta < 3.14) sec = 2;
-                else if (theta >= pi && theta < ((4. / 3.) * pi)) sec = 3;
-                else if (theta >= ((4. / 3.) * pi) && theta < ((5. / 3.) * pi)) sec = 4;
-                else sec = 5;
-                P.sector[i] = sec;
+                P.sector[i] = sector_of_draw(d);
             }
         }
         if (GLIBC) {

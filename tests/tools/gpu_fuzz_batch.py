@@ -37,8 +37,9 @@ for k in range(ncalls):
         if rs.rand() < 0.3:
             kw["max_steps"] = int(rs.randint(1, 4000))
         v, s = int(rs.randint(0, 2)), int(rs.randint(0, 1 << 31))
-        cfgs.append(pkg.make_cfg(nUE, variant=v, rng_mode=pkg.RNG_PHILOX, seed=s, **kw))
-        descs.append((v, nUE, kw, s))
+        sect = int(v == 1 and rs.rand() < 0.25)  # the dormant per-sector grant path (WithNOMA only), on the batch kernel too
+        cfgs.append(pkg.make_cfg(nUE, variant=v, rng_mode=pkg.RNG_PHILOX, seed=s, flags=pkg.FLAG_SECTOR_GRANTS if sect else 0, **kw))
+        descs.append((v, nUE, kw, s, sect))
     try:
         res, logs = eng.run_trials(cfgs, want_logs=True)
     except Exception as e:
@@ -50,8 +51,8 @@ for k in range(ncalls):
     tkr += tm.trial_kernel_reruns
 
     def one(j):
-        v, nUE, kw, s = descs[j]
-        return ob.run_trial(ob.make_cfg(nUE, variant=v, **kw), ob.Rng(ob.RNG_PHILOX, s))
+        v, nUE, kw, s, sect = descs[j]
+        return ob.run_trial(ob.make_cfg(nUE, variant=v, sector_grants=sect, **kw), ob.Rng(ob.RNG_PHILOX, s))
     with ThreadPoolExecutor(max_workers=8) as ex:
         outs = list(ex.map(one, range(len(cfgs))))
     for j, (ores, oues) in enumerate(outs):
