@@ -540,7 +540,9 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
                                                "w:phaseA|A-barrier", "w:loads", "w:refill", "t:buckets", "-", "-", "-", "-"};
             static const char *const nmb[24] = {"head", "walk", "walk-barrier", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "-", "-", "-",
                                                 "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_batch.hip
-            const char *const *const names = e->last.rec_mode == CLUSTER_REC_BATCH ? nmb : nm;
+            static const char *const nmn[24] = {"head", "publish+gather", "gather-barrier", "resolve(w0)", "resolve-barrier", "passB+A(w0)", "pass-barrier", "-", "r:to-gains", "r:rank+sort", "r:pairing", "-", "-", "-", "-", "-",
+                                                "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_noma.hip, per SUBFRAME (x accessTime = per slot)
+            const char *const *const names = noma ? nmn : e->last.rec_mode == CLUSTER_REC_BATCH ? nmb : nm;
             std::fprintf(stderr, "[prach fine stamps/step]");
             for (int q = 0; q < 20; q++) if (names[q][0] != '-') std::fprintf(stderr, " %s=%.0f", names[q], dr.fstamps[q] / (double)dr.steps);
             std::fprintf(stderr, "\n");

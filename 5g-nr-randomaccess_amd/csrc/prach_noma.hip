@@ -30,6 +30,15 @@
 #include "prach_device_fn.h"
 #include <limits.h>
 
+#ifdef PRACH_STAMPS
+#define NSTAMP(k)                                                                                      \
+    do {                                                                                               \
+        if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); fstamps[k] += now_ - fprev; fprev = now_; } \
+    } while (0)
+#else
+#define NSTAMP(k) do { } while (0)
+#endif
+
 #pragma clang fp contract(off) // (a * b + c stays two roundings, as in the reference built for baseline x86-64)
 
 namespace prach {
@@ -269,8 +278,12 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     }
     __syncthreads();
 
+#ifdef PRACH_STAMPS // (make DIAG=1; PRACH_PRINT_STAMPS=1 prints them per SUBFRAME: x accessTime = per slot; workgroup 0, wavefront 0)
+    unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
+#endif
     for (int s = 0, t0 = 0; t0 < P.stop && status == PRACH_OK; s++, t0 += aT) {
         const int t = t0; // the slot's subframe (time % accessTime == 0)
+        NSTAMP(0); // loop head
         activeCheck = P.sched[s]; // NOMA.c:675-681 (clamped running sum == the arrival table)
         const int acNext = t0 + aT < P.stop ? P.sched[s + 1] : activeCheck; // the next slot's arrivals (none after the last slot)
         const unsigned tag = (unsigned)(s + 1);
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     if (wv != NGR_NONE) atomicMin(&L.twho[bin], (int)wv);
                 }
             }
+            NSTAMP(1); // publish + bins gathered
             if (tid >= WG_THREADS - 64) { // headers: successes so far, latest success subframe
                 const int l = tid - (WG_THREADS - 64);
                 int ns = 0, mt = -1;
@@ -320,6 +334,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                 if (l == 0) { L.scal[N_NSUCCTOT] = ns; L.scal[N_MAXTTOT] = mt; }
             }
             __syncthreads();
+            NSTAMP(2); // barrier behind the gather
             if (L.scal[N_STATUS] != PRACH_OK) { status = L.scal[N_STATUS]; break; }
             nsucc_tot = L.scal[N_NSUCCTOT]; maxt_tot = L.scal[N_MAXTTOT];
         }
@@ -339,6 +354,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                 } else {
                     if (single) { L.sidx[sct * 64 + pos] = myidx; L.sg[sct * 64 + pos] = gain[myidx]; L.slg[sct * 64 + pos] = lgain[myidx]; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    NSTAMP(8); // resolve: gains loaded
                     // stable ascending rank by gain == the bubble sort with strict < (NOMA.c:90-103)
                     int uidx = -1;
                     double ug = 0, ulg = 0;
@@ -359,6 +375,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     int cidx = -1;
                     double clg = 0;
                     if (lane < count) { cidx = L.sidx[sct * 64 + lane]; clg = L.slg[sct * 64 + lane]; }
+                    NSTAMP(9); // resolve: ranked and sorted
                     unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
                     int grants = 0, npd = 0;
                     bool grantme = false;
@@ -394,13 +411,16 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         const unsigned long long lm = __ballot(left);
                         if (left && __popcll(lm & lanemask_lt(lane)) < nGrantUL - grants) grantme = true;
                     }
+                    NSTAMP(10); // resolve: paired
                     if (grantme && ((cidx >> 6) % G) == b) grant_rec(&P.rec[cidx]);
                     if (b == 0 && lane == 0 && npd) atomicAdd(&L.scal[N_PAIRD], npd);
                     if (__any(ambiguous) && lane == 0) L.scal[N_AMBIG] = 1;
                 }
             }
         }
+        NSTAMP(3); // resolve (sector 0), rest
         __syncthreads();
+        NSTAMP(4); // barrier behind the resolve
         // ---- pass B: msg2Results for the slot's transmitters, then resourceRequestAllocation for the slot's
         //      subframe and the accessTime-1 following ones, all on registers (one load / store per slot) ----
         {
@@ -506,7 +526,9 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             c_succ = wave_sum(c_succ); c_maxt = wave_max(c_maxt);
             if (lane == 0 && c_succ) { atomicAdd(&L.scal[N_NSUCC], c_succ); atomicMax(&L.scal[N_MAXT], c_maxt); }
         }
+        NSTAMP(5); // pass B + next pass A
         __syncthreads();
+        NSTAMP(6); // barrier behind the pass
     }
     __syncthreads();
 
@@ -568,6 +590,9 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             o->time_exit = time_exit;
             o->activeCheck = activeCheck;
             o->steps = (unsigned long long)tend;
+#ifdef PRACH_STAMPS
+            for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];
+#endif
         }
     }
 }
