@@ -90,6 +90,11 @@ template <int NWB> struct BL {
     static_assert(SIDX % 16 == 0 && LIST % 16 == 0 && (2 * (C::LCAP + 4 * BPF)) % 16 == 0, "alignment");
 };
 static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
+// The reference's own rand() stream (GLIBC instantiation, 1024 threads): per 64-UE group of the trial, the lanes that make at least one / two rand()
+// calls in this subframe (two 64-bit masks) and the group's exclusive prefix of calls in index order.  BGG groups = 131 072 UEs at most.
+constexpr int BGG = 2048;
+struct BLG { static constexpr int GM = BL<16>::END, GPRE = GM + 16 * BGG, END = GPRE + 4 * BGG; };
+static_assert(BLG::END <= 160 * 1024 && BLG::GM % 16 == 0, "LDS");
 
 #define BI(off) (reinterpret_cast<int *>(smem + (off)))
 #define BU(off) (reinterpret_cast<unsigned *>(smem + (off)))
@@ -121,8 +126,13 @@ __device__ __forceinline__ int4 cold_pack(const unsigned nd, const ColdRegs &c, 
 } // namespace
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-template <int NWB>
+// GLIBC: the draws of a subframe come from the reference's own rand() stream (window PD->stream, generated on the device before the launch) at
+// the positions the reference's index-ordered UE loop reaches: the event body runs twice — a COUNT pass (catch-up, activation and ue_plan only: how
+// many calls each event UE makes follows from its pre-step state) that marks the calling lanes of every group, a block-wide prefix over
+// the groups in index order, then the full body as the SELECT pass with d1, d2 = stream[base + prefix[group] + calls of the group's lower lanes].
+template <int NWB, bool GLIBC = false>
 __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restrict__ params) {
+    static_assert(!GLIBC || NWB == 16, "the reference-stream form exists in the 1024-thread shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using bl = BL<NWB>;
     constexpr int TB = NWB * 64, BEV = BCap<NWB>::EV, BQ = BCap<NWB>::Q, BLCAP = BCap<NWB>::LCAP;
@@ -152,6 +162,11 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     unsigned short *const lst = reinterpret_cast<unsigned short *>(smem + bl::LIST) + w * (BLCAP + 4 * BPF); // this wavefront's live groups
     int *const histx = BI(bl::HISTX), *const mlocx = BI(bl::MLOCX);
     int *const stage = BI(bl::STAGE) + w * (BSTG + 64);
+    unsigned *const gm = BU(BLG::GM);  // (GLIBC only) [BGG][4]: lanes with >= 1 call (two words), lanes with 2 calls (two words)
+    int *const gpre = BI(BLG::GPRE);   // (GLIBC only) [BGG]
+    const PRACH_G int *const stream = (const PRACH_G int *)PD->stream;
+    const unsigned long long stream_len = PD->stream_len;
+    unsigned long long base = 0; // GLIBC: rand() calls consumed so far (relative to the stream window)
 
     const int totgroups = (nUE + 63) >> 6;
     // calloc + initialUE (Beta.c:78-83)
@@ -164,6 +179,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         BI(bl::FCALL)[tid] = INT_MAX; BI(bl::FCALL)[NPB + tid] = INT_MAX; BI(bl::LCALL)[tid] = -1; BI(bl::LCALL)[NPB + tid] = -1;
     }
     if (tid < 64) scal[tid] = 0;
+    if (GLIBC) for (int k = tid; k < 4 * BGG; k += TB) gm[k] = 0u;
     if (lane < 4 * BPF) lst[lane] = (unsigned short)totgroups; // empty list: padding entries only
     __syncthreads();
 
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     int nlive = 0; // entries of this wavefront's list (wave-uniform)
     int why = 0;   // which per-subframe capacity ended the trial (reported)
     unsigned long long steps = 0;
-    int status = (nP > NPB || K.maxRar > 64 || stop > 65000 || totgroups > BGROUPS || nUE >= (1 << 20)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (nP > NPB || K.maxRar > 64 || stop > 65000 || totgroups > (GLIBC ? BGG : BGROUPS) || nUE >= (1 << 20)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
 #ifdef PRACH_STAMPS
     unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
 #endif
@@ -298,9 +314,9 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         BSTAMP(2);
 
         // ================= the event body: queued UEs, 64 at a time =================
+        const int qn = scal[B_QN];
         {
             int c_succ = 0, c_contf = 0;
-            const int qn = scal[B_QN];
             const int tmod = t % aT;
             const CallTables tab{fcallB, lcallB};
             struct Batch { int e; bool v; BRec R; };
@@ -313,57 +329,108 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 B.R = brec_load(rec32 + 2 * (size_t)(B.e & 0x7FFFFFFF));
                 return B;
             };
-            Batch Bn = fetch_batch(w * 64);
-            for (int q0 = w * 64; q0 < qn; q0 += NWB * 64) {
-                const Batch Bc = Bn;
-                if (q0 + NWB * 64 < qn) Bn = fetch_batch(q0 + NWB * 64); // in flight while this batch is worked on
-                const bool v = Bc.v;
-                const int e = Bc.e;
-                const int i = e & 0x7FFFFFFF;
-                const bool granted = e < 0;
-                BRec R = Bc.R;
-                if (!v) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
-                UeState u = unpack(R.a);
-                ColdRegs cold = cold_unpack(R.b);
-                unsigned nd = (unsigned)R.b.x;
-                if (v) pw_catch_up(u, (unsigned)R.b.w, granted, i, t, K.fmA, tab);
-                if (v && i >= prevAC && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
-                    ue_activate(u, i, t, cold);
-                    if (withnoma) nd = 2;
-                }
-                const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
-                int d1 = 0, d2 = 0;
-                if (__any(pl.need > 0)) {
-                    d1 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd, (unsigned)nUE, (unsigned)variant);
-                    if (__any(pl.need > 1)) d2 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd + 1u, (unsigned)nUE, (unsigned)variant);
-                    nd += (unsigned)pl.need;
-                }
-                const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
-                // ---- bucket bookkeeping ----
-                if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
-                if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i);
-                if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i);
-                {
-                    const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(o.eclass);
-                    if (em | cm) {
-                        int b_ev = 0, b_cd = 0;
-                        if (lane == 0) {
-                            if (em) b_ev = atomicAdd(&scal[B_NEV], __popcll(em));
-                            if (cm) b_cd = atomicAdd(&scal[B_NCAND], __popcll(cm));
+            // MODE 0: Philox, everything in one pass.  MODE 1 (GLIBC): the count pass — nothing is stored but the calling lanes.  MODE 2 (GLIBC): the full
+            // body with the draws at their stream positions (sbase: position of the subframe's first call of the UE loop).
+            auto body_pass = [&](auto MODE_, const unsigned long long sbase) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(MODE_)::value;
+                Batch Bn = fetch_batch(w * 64);
+                for (int q0 = w * 64; q0 < qn; q0 += NWB * 64) {
+                    const Batch Bc = Bn;
+                    if (q0 + NWB * 64 < qn) Bn = fetch_batch(q0 + NWB * 64); // in flight while this batch is worked on
+                    const bool v = Bc.v;
+                    const int e = Bc.e;
+                    const int i = e & 0x7FFFFFFF;
+                    const bool granted = e < 0;
+                    BRec R = Bc.R;
+                    if (!v) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
+                    UeState u = unpack(R.a);
+                    ColdRegs cold = cold_unpack(R.b);
+                    unsigned nd = (unsigned)R.b.x;
+                    if (v) pw_catch_up(u, (unsigned)R.b.w, granted, i, t, K.fmA, tab);
+                    if (v && i >= prevAC && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
+                        ue_activate(u, i, t, cold);
+                        if (withnoma) nd = 2;
+                    }
+                    const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
+                    const int g_ = i >> 6, ln = i & 63;
+                    if (MODE == 1) {
+                        if (v && pl.need >= 1) {
+                            atomicOr(&gm[4 * g_ + (ln >> 5)], 1u << (ln & 31));
+                            if (pl.need == 2) atomicOr(&gm[4 * g_ + 2 + (ln >> 5)], 1u << (ln & 31));
                         }
-                        b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
-                        if (o.evtype != UEV_NONE) {
-                            const int es = b_ev + __popcll(em & lanemask_lt(lane));
-                            ev_set(es, i, ue_event_info(o));
+                        continue;
+                    }
+                    int d1 = 0, d2 = 0;
+                    if (MODE == 2) {
+                        if (v && pl.need > 0) { // the UE's position inside its group from the two lane masks
+                            const unsigned lo_ = ln < 32 ? (1u << ln) - 1u : 0xffffffffu, hi_ = ln < 32 ? 0u : (1u << (ln - 32)) - 1u;
+                            const int before = __popc(gm[4 * g_] & lo_) + __popc(gm[4 * g_ + 1] & hi_) + __popc(gm[4 * g_ + 2] & lo_) + __popc(gm[4 * g_ + 3] & hi_);
+                            const unsigned long long o_ = sbase + (unsigned long long)gpre[g_] + (unsigned long long)before;
+                            d1 = stream[o_];
+                            if (pl.need > 1) d2 = stream[o_ + 1];
                         }
-                        if (o.eclass) store_i2(&cand[b_cd + __popcll(cm & lanemask_lt(lane))], i, o.oldp);
+                    } else if (__any(pl.need > 0)) {
+                        d1 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd, (unsigned)nUE, (unsigned)variant);
+                        if (__any(pl.need > 1)) d2 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd + 1u, (unsigned)nUE, (unsigned)variant);
+                        nd += (unsigned)pl.need;
+                    }
+                    const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
+                    // ---- bucket bookkeeping ----
+                    if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
+                    if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i);
+                    if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i);
+                    {
+                        const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(o.eclass);
+                        if (em | cm) {
+                            int b_ev = 0, b_cd = 0;
+                            if (lane == 0) {
+                                if (em) b_ev = atomicAdd(&scal[B_NEV], __popcll(em));
+                                if (cm) b_cd = atomicAdd(&scal[B_NCAND], __popcll(cm));
+                            }
+                            b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
+                            if (o.evtype != UEV_NONE) {
+                                const int es = b_ev + __popcll(em & lanemask_lt(lane));
+                                ev_set(es, i, ue_event_info(o));
+                            }
+                            if (o.eclass) store_i2(&cand[b_cd + __popcll(cm & lanemask_lt(lane))], i, o.oldp);
+                        }
+                    }
+                    if (v) {
+                        const unsigned word = pw_schedule<false>(u, t, K.maxRar);
+                        brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, cold, word));
+                        pw[i] = word;
                     }
                 }
-                if (v) {
-                    const unsigned word = pw_schedule<false>(u, t, K.maxRar);
-                    brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, cold, word));
-                    pw[i] = word;
+            };
+            if (!GLIBC) body_pass(std::integral_constant<int, 0>{}, 0ull);
+            else {
+                // activateUEs' two rand() calls per arrival (WithNOMA:393-394) come first in the subframe, in index order; nothing reads them here
+                const unsigned long long actdraws = withnoma ? 2ull * (unsigned long long)(activeCheck - prevAC) : 0ull;
+                body_pass(std::integral_constant<int, 1>{}, 0ull);
+                __syncthreads(); // the calling lanes of every group are marked
+                {
+                    constexpr int PERG = BGG / TB; // consecutive groups per thread
+                    int vv[PERG], sum = 0;
+#pragma unroll
+                    for (int u_ = 0; u_ < PERG; u_++) {
+                        const uint4 m = *reinterpret_cast<const uint4 *>(&gm[4 * (tid * PERG + u_)]);
+                        vv[u_] = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+                        sum += vv[u_];
+                    }
+                    const int x = wave_scan_incl(sum);
+                    if (lane == 63) BI(bl::WTOT)[w] = x;
+                    __syncthreads();
+                    int run = x - sum;
+                    for (int k = 0; k < w; k++) run += BI(bl::WTOT)[k];
+#pragma unroll
+                    for (int u_ = 0; u_ < PERG; u_++) { gpre[tid * PERG + u_] = run; run += vv[u_]; } // exclusive prefix in index order
+                    if (tid == TB - 1) scal[B_NCROSS] = run; // (free here: only the grant selection uses it)
                 }
+                __syncthreads();
+                const unsigned long long tot = actdraws + (unsigned long long)scal[B_NCROSS];
+                if (base + tot > stream_len) { status = PRACH_ERR_STREAM; time_exit = t; break; } // (the engine retries with a larger window)
+                body_pass(std::integral_constant<int, 2>{}, base + actdraws);
+                base += tot;
             }
             if (__any((c_succ | c_contf) != 0)) {
                 c_succ = wave_sum(c_succ); c_contf = wave_sum(c_contf);
@@ -387,6 +454,11 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                     ev_set(es, c.x, EVB_LEAVER | (c.y << 4));
                 }
             }
+            if (GLIBC) // every draw of this subframe has been read: the marks of the groups the queued UEs are in can go
+                for (int q = tid; q < qn; q += TB) {
+                    const int e = q < BQ ? queue[q] : qov[q - BQ];
+                    *reinterpret_cast<uint4 *>(&gm[4 * ((e & 0x7FFFFFFF) >> 6)]) = make_uint4(0u, 0u, 0u, 0u);
+                }
             if (tid < NPB) { lcallB[tid] = -1; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; }
             if (tid == 0) {
                 scal[B_EVENTS] += scal[B_QN]; // (reported, never read by the simulation)
@@ -694,7 +766,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     if (tid == 0) { // DevResult was zeroed by the engine before the launch
         PRACH_G DevResult *o = (PRACH_G DevResult *)PD->out;
         o->sumTimer = *reinterpret_cast<long long *>(&scal[B_SUMT]);
-        o->draws = *reinterpret_cast<unsigned long long *>(&scal[B_ND]);
+        o->draws = GLIBC ? base : *reinterpret_cast<unsigned long long *>(&scal[B_ND]);
         o->ptcSum = scal[B_PTC]; o->fcSum = scal[B_FC];
         o->nSuccess = scal[B_NSUCC]; o->finalSuccess = scal[B_NSUCC]; o->continueFailed = scal[B_CONTF];
         o->status = status;
@@ -711,19 +783,23 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     }
 }
 
-size_t batch_kernel_lds_bytes(int waves) { return waves == 8 ? (size_t)BL<8>::END : (size_t)BL<16>::END; }
+size_t batch_kernel_lds_bytes(int waves, bool glibc) { return glibc ? (size_t)BLG::END : waves == 8 ? (size_t)BL<8>::END : (size_t)BL<16>::END; }
 int batch_max_preambles() { return NPB; }
 int batch_max_rar_window() { return 64; }
 int batch_max_subframes() { return 65000; }
-int batch_max_groups() { return BGROUPS; }
+int batch_max_groups(bool glibc) { return glibc ? BGG : BGROUPS; }
 
 // waves: wavefronts per workgroup — 8: 512 threads, two workgroups (two independent trials) per CU; 16: 1024 threads, one per CU
-hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, int waves, hipStream_t stream) {
-    const size_t lds = batch_kernel_lds_bytes(waves);
-    const void *fn = waves == 8 ? reinterpret_cast<const void *>(&batch_kernel<8>) : reinterpret_cast<const void *>(&batch_kernel<16>);
+// glibc: the trials draw from the reference's own rand() stream (1024 threads only)
+hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, int waves, bool glibc, hipStream_t stream) {
+    if (glibc) waves = 16;
+    const size_t lds = batch_kernel_lds_bytes(waves, glibc);
+    const void *fn = glibc ? reinterpret_cast<const void *>(&batch_kernel<16, true>)
+                           : waves == 8 ? reinterpret_cast<const void *>(&batch_kernel<8>) : reinterpret_cast<const void *>(&batch_kernel<16>);
     hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc != hipSuccess) return rc;
-    if (waves == 8) hipLaunchKernelGGL(batch_kernel<8>, dim3(ntrials), dim3(512), lds, stream, params);
+    if (glibc) hipLaunchKernelGGL((batch_kernel<16, true>), dim3(ntrials), dim3(1024), lds, stream, params);
+    else if (waves == 8) hipLaunchKernelGGL(batch_kernel<8>, dim3(ntrials), dim3(512), lds, stream, params);
     else hipLaunchKernelGGL(batch_kernel<16>, dim3(ntrials), dim3(1024), lds, stream, params);
     return hipGetLastError();
 }

@@ -111,12 +111,12 @@ constexpr size_t CLUSTER_LDS_LIMIT = 160 * 1024; // LDS per CU (MI355X_MICROARCH
 hipError_t launch_cluster_kernel(const TrialDev *params, int ntrials, int G, int maxP, int rng_mode, int rec_mode, int lslots, int xpack, hipStream_t stream);
 int cluster_kernel_blocks_per_cu(int maxP, int rng_mode, int rec_mode, int lslots); // occupancy query for the kernel and its dynamic LDS size
 constexpr int CLUSTER_REC_BATCH = 4; // prach_batch.hip: one workgroup per trial, 4-byte pass words + 32-byte event records (Philox)
-size_t batch_kernel_lds_bytes(int waves);
+size_t batch_kernel_lds_bytes(int waves, bool glibc = false);
 int batch_max_preambles();
 int batch_max_rar_window();
 int batch_max_subframes();
-int batch_max_groups();
-hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, int waves, hipStream_t stream);
+int batch_max_groups(bool glibc = false);
+hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, int waves, bool glibc, hipStream_t stream);
 constexpr int STREAM_CHUNK = 31 * 2048; // rand() outputs generated per wavefront (prach_stream.hip)
 hipError_t launch_glibc_stream(const unsigned *seeds, int *out, unsigned long long n, hipStream_t stream);
 extern "C" void prach_internal_glibc_seeds(uint32_t seed, uint64_t first, uint64_t nchunks, uint64_t chunk, uint32_t *out);

@@ -37,6 +37,7 @@ struct prach_engine {
     size_t pinned_cap = 0;
     prach_timing last{};
     int64_t opt_stream_factor = 0; // glibc: initial draws-per-UE budget override (0 = auto)
+    double draws_per_ue_seen = 0;  // glibc: the largest rand() consumption per UE of the last call's trials (0: none yet) — sizes the next call's stream windows
     int64_t opt_cluster = 0;       // workgroups per trial for the Philox cluster kernel (0 = auto)
     int64_t opt_legacy = 0;        // 1: run Philox trials on the one-workgroup trial_kernel as well
     int64_t opt_dense = 0;         // 1: cluster kernel without the compacted pass (diagnostic)
@@ -154,18 +155,23 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
 }
 
 // initial glibc stream budget (draws) for a trial; the kernel reports exhaustion and we retry bigger
-uint64_t stream_budget(const prach_cfg &c, int attempt, int64_t factor) {
-    uint64_t per = factor > 0 ? (uint64_t)factor : 450; // 100k UEs / 12 grants / backoff 20 consume ~325 per UE
+// (a sweep is called point after point with growing nUE: what the previous point's trials consumed per UE, tripled, is the first window of the next —
+//  a Beta.c point with 54 grants draws ~30 values per UE, not 450: 100 seeds x 100 000 UEs are then 3 GB of windows instead of 18 GB; a window that
+//  turns out too small is the ordinary PRACH_ERR_STREAM retry, four times larger)
+uint64_t stream_budget(const prach_cfg &c, int attempt, int64_t factor, double seen) {
+    uint64_t per = factor > 0 ? (uint64_t)factor : seen > 0 ? (uint64_t)std::min(450.0, std::max(64.0, 3.0 * seen + 32.0)) : 450; // 100k UEs / 12 grants / backoff 20 consume ~325 per UE
     uint64_t b = (uint64_t)c.nUE * per + (1u << 20);
     return b << (2 * attempt);
 }
 
 int ensure_arena(prach_engine *e, size_t need) {
     if (need <= e->arena_cap) return PRACH_OK;
+    const size_t had = e->arena_cap;
     if (e->arena) HIPCHK(hipFree(e->arena));
     e->arena = nullptr;
     e->arena_cap = 0;
-    const size_t want = need + (need >> 3);
+    // (a sweep's calls grow point by point: growing by an eighth re-allocated at nearly every point, and one hipFree + hipMalloc of ~16 GB measured 1.4 s)
+    const size_t want = std::max(need + (need >> 2), std::min<size_t>(2 * had, (size_t)64 << 30));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&e->arena), want));
     e->arena_cap = want;
     return PRACH_OK;
@@ -247,11 +253,14 @@ static bool use_fast_kernel(const prach_engine *e, int lslots, int maxP) {
     return lslots > 0 && e->opt_fast && e->opt_pipeline && maxP <= lcluster_max_preambles() && lcluster_kernel_lds_bytes(lslots) <= CLUSTER_LDS_LIMIT;
 }
 
-// one workgroup per trial, Philox: can prach::batch_kernel (prach_batch.hip) run this trial?
+// one workgroup per trial: can prach::batch_kernel (prach_batch.hip) run this trial?  (Philox: both workgroup shapes; the reference's own rand()
+// stream: the 1024-thread shape with its per-group call marks in LDS, up to 131 072 UEs, not the per-sector grant path)
 static bool batch_eligible(const prach_engine *e, const prach_cfg &c) {
-    if (c.variant == PRACH_VARIANT_NOMA_C || c.rng_mode != PRACH_RNG_PHILOX || !e->opt_batch || e->opt_dense || e->opt_wide_records) return false;
+    if (c.variant == PRACH_VARIANT_NOMA_C || !e->opt_batch || e->opt_dense || e->opt_wide_records) return false;
+    const bool glibc = c.rng_mode == PRACH_RNG_GLIBC;
+    if (glibc && (c.flags & PRACH_FLAG_SECTOR_GRANTS)) return false;
     return c.nPreamble <= batch_max_preambles() && c.maxRarWindow <= batch_max_rar_window() &&
-           (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups();
+           (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups(glibc);
 }
 
 // NOMA.c's activeUE table on the device: noma_activation_kernel for every UE of the launch, then the few UEs whose value sits within the
@@ -301,7 +310,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     int maxP = 1;
     for (int k = 0; k < m; k++) {
         const prach_cfg &c = cfgs[idx[k]];
-        if (rng_mode == PRACH_RNG_GLIBC) slen[k] = (size_t)stream_budget(c, attempt, e->opt_stream_factor);
+        if (rng_mode == PRACH_RNG_GLIBC) slen[k] = (size_t)stream_budget(c, attempt, e->opt_stream_factor, e->draws_per_ue_seen);
         if (c.nPreamble > maxP) maxP = c.nPreamble;
     }
     // one workgroup per trial, Philox: the batch kernel (prach_batch.hip), within its limits
@@ -453,6 +462,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         // whole trial can serve: an event-dense body, where one 1024-thread workgroup per CU measured 3-7 % faster: 827 vs 854 ms on
         // config 3), or there are too few trials to fill the CUs twice.
         int waves = (int)e->opt_batch_waves;
+        if (rng_mode == PRACH_RNG_GLIBC) waves = 16;
         if (waves == 0) {
             double upd_all = 0, upd_over = 0;
             for (int k = 0; k < m; k++) {
@@ -464,7 +474,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             waves = (m >= 3 * e->num_cus && upd_over < 0.5 * upd_all) ? 8 : 16;
         }
         e->last.workgroups = m;
-        HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, waves, e->stream));
+        HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, waves, rng_mode == PRACH_RNG_GLIBC, e->stream));
     }
     else if (G > 0) {
         // one workgroup per trial in the reference's rand() stream: 8 + 4 byte hot records, if every subframe number of every trial of
@@ -704,7 +714,14 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
                 // two workgroups per trial are not worth their exchange: 100 sweep trials run 151 / 242 ms (Beta.c / WithNOMA) on the batch kernel, one
                 // workgroup each, against 221 / 471 ms on 2-workgroup clusters, whose halves of a 100 000-UE trial also overflow the 512 event
                 // granules of a mailbox (32 of 100 trials rerun); from four workgroups per trial on, clusters win (scripts/gpu_probe_mid_batches.py)
-                if (G == 2 && mode == PRACH_RNG_PHILOX && e->opt_batch) G = 1;
+                // (the reference's own stream, 100 trials of one sweep point: 246 / 431 ms on batch_kernel<16, true> against 657 / 2 126 ms — Beta.c / WithNOMA,
+                //  nUE = 100 000, the latter with every trial overflowing its mailboxes — on 2-workgroup clusters: scripts/gpu_probe_glibc_batches.py)
+                bool all_batch = e->opt_batch != 0;
+                for (int k : idx) all_batch = all_batch && batch_eligible(e, cfgs[k]);
+                if (G == 2 && all_batch) G = 1;
+                // (in the reference's stream also against four workgroups per trial, which run on the general kernel: 50 trials 210 / 338 ms against 351 / 501 ms
+                //  at nUE = 100 000, 73 / 100 against 84 / 108 ms at 20 000; from eight workgroups per trial on the clusters are level or ahead)
+                if (G == 4 && all_batch && mode == PRACH_RNG_GLIBC) G = 1;
                 bool light = mode == PRACH_RNG_PHILOX;
                 for (int k : idx) light = light && cfgs[k].uniform && cfgs[k].nUE <= 2000000;
                 if (light) G = 1;
@@ -738,9 +755,11 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             }
             e->pack_off = false;
             idx.swap(fallback);
-            if (!idx.empty()) note_fallback(e, (G > 1 && mode == PRACH_RNG_PHILOX && e->opt_batch) ? "prach::batch_kernel (one workgroup per trial, event queue without a capacity)"
-                                                                                                    : "trial_kernel (one workgroup per trial, no per-subframe capacity)", idx.size(), nto, G);
-            if (!idx.empty() && G > 1 && mode == PRACH_RNG_PHILOX && e->opt_batch) {
+            bool to_batch = G > 1 && e->opt_batch && !idx.empty();
+            for (int k : idx) to_batch = to_batch && batch_eligible(e, cfgs[k]);
+            if (!idx.empty()) note_fallback(e, to_batch ? "prach::batch_kernel (one workgroup per trial, event queue without a capacity)"
+                                                        : "trial_kernel (one workgroup per trial, no per-subframe capacity)", idx.size(), nto, G);
+            if (to_batch) {
                 // Overflow without the cliff: most capacities a cluster trips over are PER WORKGROUP (512 event granules per mailbox, the
                 // candidate list) or come with its LDS-resident layout; prach::batch_kernel has neither (one workgroup, the event queue
                 // continues in global memory) and still runs all 16 wavefronts on the trial, so such trials go there first — the
@@ -769,10 +788,13 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
     }
     uint64_t upd = 0;
     int worst = PRACH_OK;
+    double seen = 0;
     for (int k = 0; k < n; k++) {
         upd += (uint64_t)cfgs[k].nUE * results[k].steps;
         if (results[k].status != PRACH_OK) worst = results[k].status;
+        else if (cfgs[k].rng_mode == PRACH_RNG_GLIBC && cfgs[k].variant != PRACH_VARIANT_NOMA_C) seen = std::max(seen, (double)results[k].draws / (double)cfgs[k].nUE);
     }
+    if (seen > 0) e->draws_per_ue_seen = seen; // (sizes the stream windows of the next call: stream_budget)
     e->last.kernel_ms = kernel_ms;
     e->last.noma_host_ues = e->noma_flagged;
     e->last.upload_ms = upload_ms;

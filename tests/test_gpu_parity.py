@@ -87,6 +87,51 @@ def test_gpu_reproduces_reference_files(pkg, engine, case):
         assert hashlib.sha256(text).hexdigest() == tr["logs_sha256"], (case, tr["nUE"])
 
 
+@pytest.mark.parametrize("case", ["beta", "noma_default"])
+def test_gpu_batch_kernel_in_the_reference_stream(pkg, ob, engine, case):
+    """prach::batch_kernel<16, true> — one workgroup per trial, the draws at their positions in the reference's own rand() stream (count pass, prefix
+    over the groups in index order, select pass) — is what `prach_sim -t 100` runs per sweep point.  (1) The reference's own run, chained through
+    the stream offsets, with one workgroup per trial: Results.txt, stdout block and Logs.txt SHA-256 of every trial up to nUE = 100 000;
+    (2) several seeds of one point in ONE call (as the CLI issues them) against the oracle, every field of every UE."""
+    g = load_golden(case)
+    variant = 0 if g["variant"] == "BETA_C" else 1
+    blocks = split_stdout_blocks(g["stdout"])
+    engine.set("cluster", 1)
+    try:
+        offsets = {}
+        for k, tr in enumerate(g["trials"]):
+            off = offsets.get(tr["seed"], 0)
+            cfg = pkg.make_cfg(tr["nUE"], variant=variant, rng_mode=pkg.RNG_GLIBC, seed=tr["seed"], stream_offset=off, **g["cfg_overrides"])
+            (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+            tm = engine.timing()
+            assert res.status == 0 and tm.rec_mode == 4 and tm.fallback_trials == 0, (case, tr["nUE"], tm.rec_mode)
+            offsets[tr["seed"]] = off + res.draws
+            txt = pkg.format_results(cfg, res, 0.0).decode()
+            if variant == 0:
+                txt = txt[:-len("0.000000")]
+            assert txt == tr["results_text"], (case, tr["nUE"])
+            so = pkg.format_stdout(cfg, res, 0.0).decode()
+            so = "".join(l + "\n" for l in so.split("\n") if l and not l.startswith("Latency:"))
+            assert so == blocks[k], (case, tr["nUE"])
+            text = pkg.format_logs(logs, tr["nUE"])
+            assert len(text) == tr["logs_bytes"] and hashlib.sha256(text).hexdigest() == tr["logs_sha256"], (case, tr["nUE"])
+    finally:
+        engine.set("cluster", 0)
+    # as the CLI issues a sweep point: many seeds in one call, automatic cluster size (100+ trials: one workgroup each)
+    kw = dict(nGrantUL=12) if variant else {}
+    cfgs = [pkg.make_cfg(20000, variant=variant, rng_mode=pkg.RNG_GLIBC, seed=s, stream_offset=1000 * s, **kw) for s in range(130)]
+    res, logs = engine.run_trials(cfgs, want_logs=True)
+    tm = engine.timing()
+    assert tm.rec_mode == 4 and tm.cluster_size == 1 and tm.fallback_trials == 0
+    for s in (0, 57, 129):
+        rng = ob.Rng(ob.RNG_GLIBC, s)
+        for _ in range(1000 * s):  # (the trial starts 1000 s values into its seed's stream)
+            rng.next_glibc()
+        ores, oues = ob.run_trial(ob.make_cfg(20000, variant=variant, **kw), rng)
+        assert_same(pkg, res[s], logs[s], ores, oues, ("glibc batch", case, s))
+    assert len({(r.nSuccessUE, r.draws) for r in res}) > 100  # (different seeds: different trials)
+
+
 def test_full_size_100k_vs_oracle_and_properties(pkg, ob, engine):
     """BASELINE config 2 (nUE=100 000, Beta, 54 preambles, retx 10) at full size."""
     n = 100000

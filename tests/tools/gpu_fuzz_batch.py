@@ -1,5 +1,5 @@
 """Fuzz prach::batch_kernel (one workgroup per trial, Philox) against the oracle: random configurations inside the kernel's limits,
-several trials per call.  usage: gpu_fuzz_batch.py <seed> <calls> [big]   (PRACH_LIB=...tinyq.so: the queue's global part)"""
+several trials per call.  usage: gpu_fuzz_batch.py <seed> <calls> [big] [glibc]   (PRACH_LIB=...tinyq.so: the queue's global part)"""
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,7 +16,9 @@ for kv in filter(None, os.environ.get("PRACH_ENG_OPTS", "").split(",")):  # e.g.
     eng.set(kv.split("=")[0], int(kv.split("=")[1]))
 eng.set("cluster", 1)
 seed, ncalls = int(sys.argv[1]), int(sys.argv[2])
-big = len(sys.argv) > 3
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
+GLIBC = "glibc" in sys.argv[3:]  # the reference's own rand() stream: batch_kernel<16, true>
+RNG = pkg.RNG_GLIBC if GLIBC else pkg.RNG_PHILOX
 rs = np.random.RandomState(seed)
 bad = ntr = notbatch = tkr = 0
 t0 = time.time()
@@ -37,8 +39,8 @@ for k in range(ncalls):
         if rs.rand() < 0.3:
             kw["max_steps"] = int(rs.randint(1, 4000))
         v, s = int(rs.randint(0, 2)), int(rs.randint(0, 1 << 31))
-        sect = int(v == 1 and rs.rand() < 0.25)  # the dormant per-sector grant path (WithNOMA only), on the batch kernel too
-        cfgs.append(pkg.make_cfg(nUE, variant=v, rng_mode=pkg.RNG_PHILOX, seed=s, flags=pkg.FLAG_SECTOR_GRANTS if sect else 0, **kw))
+        sect = int(v == 1 and rs.rand() < 0.25 and not GLIBC)  # the dormant per-sector grant path (WithNOMA only), on the batch kernel too
+        cfgs.append(pkg.make_cfg(nUE, variant=v, rng_mode=RNG, seed=s, flags=pkg.FLAG_SECTOR_GRANTS if sect else 0, **kw))
         descs.append((v, nUE, kw, s, sect))
     try:
         res, logs = eng.run_trials(cfgs, want_logs=True)
@@ -52,7 +54,7 @@ for k in range(ncalls):
 
     def one(j):
         v, nUE, kw, s, sect = descs[j]
-        return ob.run_trial(ob.make_cfg(nUE, variant=v, sector_grants=sect, **kw), ob.Rng(ob.RNG_PHILOX, s))
+        return ob.run_trial(ob.make_cfg(nUE, variant=v, sector_grants=sect, **kw), ob.Rng(ob.RNG_GLIBC if GLIBC else ob.RNG_PHILOX, s))
     with ThreadPoolExecutor(max_workers=8) as ex:
         outs = list(ex.map(one, range(len(cfgs))))
     for j, (ores, oues) in enumerate(outs):
