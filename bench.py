@@ -430,6 +430,18 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
                 "wall_updates_per_s_incl_host_stream_and_log_dump": 1e5 * r.steps / wall}
         except Exception as e:  # fixtures missing: report, do not fail the bench
             extras["glibc_mode_reference_point"] = {"error": repr(e)}
+        # (1b) the reference's stream with many seeds in flight: what `prach_sim -t 100` issues for the sweep's last point (the ten points of a seed are
+        # chained through its rand() stream, so a call holds one point of every seed): 100 seeds x nUE = 100 000, Beta.c, one workgroup per trial
+        cfgs = [pkg.make_cfg(args.nue, variant=pkg.VARIANT_BETA_C, rng_mode=pkg.RNG_GLIBC, seed=s) for s in range(100)]
+        eng.run_trials(cfgs[:4])  # (arena / code object warm-up)
+        t1 = time.perf_counter()
+        rs, _ = eng.run_trials(cfgs)
+        wall = time.perf_counter() - t1
+        tm_ = eng.timing()
+        upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
+        extras["glibc_mode_100_seeds_one_sweep_point"] = {"kernel": KERNEL_NAMES.get(tm_.rec_mode, "?") + " in the reference's rand() stream", "trials": len(cfgs),
+                                                          "kernel_updates_per_s": upd / (tm_.kernel_ms * 1e-3), "wall_updates_per_s": upd / wall, "kernel_ms": tm_.kernel_ms,
+                                                          "bad": sum(r_.status != 0 for r_ in rs), "fallback_trials": tm_.fallback_trials}
         # (2) the RandomAccessWithNOMA default (12 grants, overload) single trial
         cfg = pkg.make_cfg(args.nue, variant=pkg.VARIANT_WITHNOMA_C, rng_mode=pkg.RNG_PHILOX, seed=0)
         (r,), _ = eng.run_trials([cfg])
