@@ -51,7 +51,7 @@ def main():
                 if m and not m.group(1).startswith("."):
                     res[cur][classify(m.group(1))] += 1; res[cur]["total"] += 1
     names = demangle(list(res))
-    table = {names[k].replace("prach::", "").split("(")[0]: dict(res[k], **{("r_" + a): b for a, b in usage[k].items()}) for k in res}
+    table = {names[k].replace("(anonymous namespace)::", "").replace("prach::", "").split("(")[0]: dict(res[k], **{("r_" + a): b for a, b in usage[k].items()}) for k in res}
     if "--json" in sys.argv:
         print(json.dumps(table, indent=1, sort_keys=True)); return
     old = json.load(open(sys.argv[sys.argv.index("--vs") + 1])) if "--vs" in sys.argv else None
