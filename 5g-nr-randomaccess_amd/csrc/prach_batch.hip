@@ -350,6 +350,9 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                     if (v && i >= prevAC && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
                         ue_activate(u, i, t, cold);
                         if (withnoma) nd = 2;
+                        // the reference's stream has no per-UE draw index: the record's word keeps the UE's sector instead, fixed by the first of its two
+                        // activation calls (WithNOMA:393-410), which sit at the head of this subframe's calls in index order (read in the select pass: the window has been checked)
+                        if (GLIBC && sectors && MODE == 2) nd = (unsigned)sector_of_draw(stream[base + 2ull * (unsigned long long)(i - prevAC)]);
                     }
                     const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
                     const int g_ = i >> 6, ln = i & 63;
@@ -591,16 +594,21 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         if (ns > BSC) { status = PRACH_ERR_INTERNAL; why = 3; time_exit = t; break; }
         const int Gr = max(0, nGrantUL - 1 - grantCheck); // Beta.c:336-347
         auto grant = [&](const int my) { __hip_atomic_fetch_or(pw + my, PW_GRANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // ONE fire-and-forget L2 atomic
+        // a caller's sector: Philox — a function of the UE's own first activation draw, recomputed; the reference's stream — kept in the UE's record
+        auto sector_of = [&](const int my) -> int {
+            if (GLIBC) return rec32[2 * (size_t)my + 1].x;
+            return sector_of_draw(philox_draw31(seed_lo, seed_hi, (unsigned)my, 0u, (unsigned)nUE, (unsigned)variant));
+        };
         if (sectors) {
             // the dormant per-sector grant test (WithNOMA:626-637 with the call of :312): every 60-degree sector has its own budget of the 5 ms
             // window, grantCheck[sector] counts that sector's singleton callers.  A caller's sector is a function of its first activation draw
-            // (Philox: the UE's own counter, draw 0), recomputed here.  Up to one wavefront of singleton callers: ranked through v_readlane.
+            // (sector_of above).  Up to one wavefront of singleton callers: ranked through v_readlane.
             if (ns > 0 && ns <= 64) {
                 if (tid < 64) {
                     const int nsu = __builtin_amdgcn_readfirstlane(ns);
                     const bool have = tid < nsu;
                     const int my = have ? BI(bl::SIDX)[tid] : INT_MAX;
-                    const int sec = have ? sector_of_draw(philox_draw31(seed_lo, seed_hi, (unsigned)my, 0u, (unsigned)nUE, (unsigned)variant)) : 7;
+                    const int sec = have ? sector_of(my) : 7;
                     int rank = 0;
                     for (int s_ = 0; s_ < nsu; s_++) rank += (__builtin_amdgcn_readlane(my, s_) < my && __builtin_amdgcn_readlane(sec, s_) == sec) ? 1 : 0;
                     if (have && rank < nGrantUL - 1 - scal[B_SGC + sec]) grant(my);
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 __syncthreads();
                 for (int j = tid; j < ns; j += TB) {
                     const int my = sidx[j];
-                    const int sec = sector_of_draw(philox_draw31(seed_lo, seed_hi, (unsigned)my, 0u, (unsigned)nUE, (unsigned)variant));
+                    const int sec = sector_of(my);
                     sidx[j] = my | (sec << 24); // (UE indices have 20 bits)
                     atomicAdd(&bins[sec * SB + (my >> shift)], 1);
                 }

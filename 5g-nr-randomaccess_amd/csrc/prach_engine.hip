@@ -254,11 +254,10 @@ static bool use_fast_kernel(const prach_engine *e, int lslots, int maxP) {
 }
 
 // one workgroup per trial: can prach::batch_kernel (prach_batch.hip) run this trial?  (Philox: both workgroup shapes; the reference's own rand()
-// stream: the 1024-thread shape with its per-group call marks in LDS, up to 131 072 UEs, not the per-sector grant path)
+// stream: the 1024-thread shape with its per-group call marks in LDS, up to 131 072 UEs)
 static bool batch_eligible(const prach_engine *e, const prach_cfg &c) {
     if (c.variant == PRACH_VARIANT_NOMA_C || !e->opt_batch || e->opt_dense || e->opt_wide_records) return false;
     const bool glibc = c.rng_mode == PRACH_RNG_GLIBC;
-    if (glibc && (c.flags & PRACH_FLAG_SECTOR_GRANTS)) return false;
     return c.nPreamble <= batch_max_preambles() && c.maxRarWindow <= batch_max_rar_window() &&
            (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups(glibc);
 }

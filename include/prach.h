@@ -34,8 +34,8 @@ extern "C" {
 /* prach_cfg.flags: variants the reference carries as commented-out code (never executed by the programs as committed) */
 #define PRACH_FLAG_SECTOR_GRANTS   1 /* WITHNOMA_C: one UL-grant budget per 60-degree sector (sectorGrants[6], RandomAccessWithNOMA.c:260,
                                         271-273; the call of :312 and the grantCheck[sector] test of :626-637 un-commented); the sector
-                                        comes from activateUEs' first draw (WithNOMA:393-410).  Philox trials run on prach::batch_kernel
-                                        (one workgroup per trial), trials in the reference's stream on the index-ordered trial_kernel */
+                                        comes from activateUEs' first draw (WithNOMA:393-410).  Runs on prach::batch_kernel (one workgroup
+                                        per trial) in both RNG modes */
 #define PRACH_FLAG_NOMA_NONSECTOR  2 /* NOMA_C: the cell-wide grouping preambleCollisionDetection (NOMA.c:325-447, call of :688
                                         un-commented) instead of preambleSectorCollisionDetection: one nGrantUL budget per access slot */
 

@@ -39,7 +39,7 @@ for k in range(ncalls):
         if rs.rand() < 0.3:
             kw["max_steps"] = int(rs.randint(1, 4000))
         v, s = int(rs.randint(0, 2)), int(rs.randint(0, 1 << 31))
-        sect = int(v == 1 and rs.rand() < 0.25 and not GLIBC)  # the dormant per-sector grant path (WithNOMA only), on the batch kernel too
+        sect = int(v == 1 and rs.rand() < 0.25)  # the dormant per-sector grant path (WithNOMA only), on the batch kernel too
         cfgs.append(pkg.make_cfg(nUE, variant=v, rng_mode=RNG, seed=s, flags=pkg.FLAG_SECTOR_GRANTS if sect else 0, **kw))
         descs.append((v, nUE, kw, s, sect))
     try:
