@@ -614,8 +614,21 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
             const unsigned long long len = ((unsigned long long)cfgs[k].nUE * 48ull + (1ull << 18)) << (2 * attempt);
             std::vector<int32_t> hs((size_t)len);
             prach_glibc_stream((uint32_t)cfgs[k].seed, cfgs[k].stream_offset, len, hs.data());
-            rc = run_noma_glibc_trial(e->stream, cfgs[k], hs.data(), len, &results[k], ue_logs ? ue_logs[k] : nullptr, &kernel_ms);
-            e->last.launches++;
+            // one launch for the whole trial, activeUE on the device; a value inside the device math library's error band (prach_noma_act.h: ~7 % of
+            // the nUE = 100 000 trials) sends the trial to the slot-by-slot form, whose arrivals the host activates with the reference's libm
+            const bool devact = !e->opt_noma_host_activation;
+            if (devact && e->opt_noma_ambiguity_test) rc = NOMA_GLIBC_AMBIGUOUS_RC; // (test hook: as if the kernel had found a value inside the band)
+            else {
+                rc = run_noma_glibc_trial(e->stream, cfgs[k], hs.data(), len, &results[k], ue_logs ? ue_logs[k] : nullptr, &kernel_ms, devact);
+                e->last.launches++;
+            }
+            if (rc == NOMA_GLIBC_AMBIGUOUS_RC) {
+                e->noma_ambiguous++;
+                e->last.fallback_trials++;
+                if (std::getenv("PRACH_VERBOSE")) std::fprintf(stderr, "[prach] NOMA.c trial nUE=%d in the reference's stream: a value inside the device libm's error band, rerun with host-side activation\n", cfgs[k].nUE);
+                rc = run_noma_glibc_trial(e->stream, cfgs[k], hs.data(), len, &results[k], ue_logs ? ue_logs[k] : nullptr, &kernel_ms, false);
+                e->last.launches++;
+            }
         }
         if (rc != PRACH_OK) return rc;
     }

@@ -1,18 +1,22 @@
 // prach_noma_glibc.hip — NOMA.c (PRACH_VARIANT_NOMA_C) in the REFERENCE'S OWN rand() stream, on the GPU.
 //
 // Why this path is separate from prach_noma.hip: NOMA.c draws everything from one global stream, and activeUE (NOMA.c:131-192) consumes a
-// DATA-DEPENDENT number of draws per UE (two rejection loops) through double-precision libm calls (cos, sin, sqrt, log, pow) whose results
-// must be bit-identical to the reference's.  So in this mode the activation of an access slot's arrivals runs on the HOST, in stream order,
-// with the libm the reference links (prach_noma_activation_stream), between two device steps; everything else of the slot — the
-// transmitter gather, the per-sector grouping with its pair draws, msg2Results, and resourceRequestAllocation / timerIncrease /
-// successUEs of the slot's accessTime subframes — is ONE kernel launch per access slot that consumes the device copy of the stream at
-// exactly the positions the reference's index-ordered loops reach (block-wide exclusive prefix sums over the draw counts, chunk after
-// chunk in index order, phase after phase in the reference's order).  One workgroup per trial: this is the bit-exact-vs-the-reference's-own-
-// files mode of config 4 (2000 launches and host round trips per trial: ~0.3 s at nUE = 100 000), not the throughput mode (Philox,
-// prach_noma.hip).  Reference: NOMA.c:131-192 (host), :194-324 / :325-447 (grouping), :449-498 (msg2Results), :499-546
-// (resourceRequestAllocation), :665-711 (the time step).
+// DATA-DEPENDENT number of draws per UE (two rejection loops) through double-precision libm calls (cos, sin, sqrt, log, pow), so every stream
+// position is data dependent.  One workgroup per trial; the device copy of the stream is consumed at exactly the positions the reference's
+// index-ordered loops reach (block-wide exclusive prefix sums over the draw counts, chunk after chunk in index order, phase after phase in the
+// reference's order).  Two forms:
+//   * noma_glibc_trial_kernel (round 3, the default): the WHOLE trial in ONE launch.  activeUE runs on the device (prach_noma_act.h; the arrivals'
+//     stream positions by iteration), the passes run over a list of the UEs that are still alive (a band of a few thousand at nUE = 100 000),
+//     the grouping is one wavefront's rank sort + ballot pairing.  141 ms for nUE = 100 000 (round 2: 1.5 s).  The device's cos / sin / log are not
+//     the host libm's to the last bit: a value inside the error band (a float rounding boundary, the rejection threshold, two gains too
+//     close to order) ends the launch with NOMA_GLIBC_AMBIGUOUS (a few percent of the trials) and the trial is run again in the other form:
+//   * noma_glibc_slot_kernel: one launch per access slot, the slot's arrivals activated on the HOST between two launches with the libm the
+//     reference links (prach_noma_activation_stream) — bit-identical by construction, 2000 launches and host round trips per trial.
+// This is the bit-exact-vs-the-reference's-own-files mode of config 4, not the throughput mode (Philox, prach_noma.hip).  Reference:
+// NOMA.c:131-192 (activeUE), :194-324 / :325-447 (grouping), :449-498 (msg2Results), :499-546 (resourceRequestAllocation), :665-711 (the time step).
 #include "prach_device.h"
 #include "prach_device_fn.h"
+#include "prach_noma_act.h"
 
 #pragma clang fp contract(off) // (a * b + c stays two roundings, as in the reference built for baseline x86-64)
 
@@ -66,21 +70,29 @@ __device__ __forceinline__ int block_excl_scan(const int v, int *wtot, int &tot)
     return x - v + add;
 }
 
-__global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, const int *stream_, SlotCtl *ctl_, const NParams K) {
-    __shared__ int cnt[6 * 64], who[6 * 64], wtot[NW], sh[8];
-    NG NUe *const ue = (NG NUe *)ue_;
-    const NG int *const stream = (const NG int *)stream_;
-    NG SlotCtl *const ctl = (NG SlotCtl *)ctl_;
+constexpr int NOMA_GLIBC_AMBIGUOUS = -77; // (internal) a value of the device-side activation / a gain comparison fell inside the device libm's error band
+
+// One access slot (the slot's subframe `time` and the aT - 1 behind it).  live == nullptr: the passes run over every arrived UE [0, ac) as the reference's
+// loops do.  Otherwise over live[0 .. nlive): the indices, ascending, of the arrived UEs that have neither succeeded nor been dropped for good — nothing
+// ever touches the others again (every action below asks RA == 0 and RaFailed == 0), and an index-ordered prefix over the list is the prefix over all
+// UEs; succ_removed: the successes among the UEs already taken off the list.  devact: the gains were computed by the device's math library (noma_glibc_trial_kernel) — every comparison of gains is then
+// checked against the error band and reported (status NOMA_GLIBC_AMBIGUOUS: the host reruns the trial with its own libm).
+__device__ __forceinline__ void noma_glibc_slot(NG NUe *const ue, const NG int *const stream, const NParams &K, int *cnt, int *who, int *wtot, int *sh,
+                                                int *gs_idx, double *gs_g, double *gs_lg,
+                                                const int time, const int ac, const NG int *const live, const int nlive, const int succ_removed, const unsigned long long slen, const bool devact,
+                                                unsigned long long &pos_io, int &status_out, int &exit_time_out, int &nsucc_out) {
     const int tid = threadIdx.x;
-    const int nP = K.nP, aT = K.aT, time = ctl->time, ac = ctl->activeCheck;
-    const unsigned long long slen = ctl->stream_len;
-    unsigned long long pos = ctl->pos;
+    const int nP = K.nP, aT = K.aT;
+    unsigned long long pos = pos_io;
     const int nsect = K.nonsector ? 1 : 6;
+    const int nn = live ? nlive : ac; // UEs the passes look at: the live list (ascending indices) or every arrived UE
+    auto idx_of = [&](const int q) -> int { return live ? live[q] : q; };
 
     // ---- transmitter gather (NOMA.c:207-213 / :331-339): per (sector, preamble) count and lowest transmitter ----
     for (int k = tid; k < 6 * 64; k += WG_THREADS) { cnt[k] = 0; who[k] = INT_MAX; }
     __syncthreads();
-    for (int i = tid; i < ac; i += WG_THREADS) {
+    for (int q = tid; q < nn; q += WG_THREADS) {
+        const int i = idx_of(q);
         const NG NUe &u = ue[i];
         if (u.RA == 0 && u.txTime == time + 1 && u.msg2 == 0 && u.nowBackoff <= 0 && u.RaFailed == 0) {
             const int b = (K.nonsector ? 0 : u.sector) * nP + u.preamble;
@@ -89,63 +101,79 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, c
         }
     }
     __syncthreads();
-    // ---- grouping, sequentially like the reference (NOMA.c:214-309 per sector / :341-437 cell-wide): ONE thread; sectors in order, the
-    // pair draws straight from the stream ----
-    if (tid == 0) {
+    // ---- grouping (NOMA.c:214-309 per sector / :341-437 cell-wide) by ONE wavefront, sectors in order because the pair draws come straight from the
+    // stream: lane = preamble.  Singleton transmitters in preamble order (ballot compaction), stable ascending rank by gain == the reference's bubble
+    // sort with strict < (NOMA.c:90-103), greedy pairing over the sorted lanes (ballot + find-first), leftovers while grants remain — prach_noma.hip's
+    // resolver with the reference's stream instead of a counter.  (Before: one thread and the O(count^2) bubble sort on scratch arrays, ~1 ms per slot.)
+    if (tid < 64) {
+        const int lane = tid;
         int status = PRACH_OK;
-        for (int s = 0; s < nsect; s++) {
-            int tidx[64];
-            double tg[64], tl[64];
-            int count = 0;
-            for (int p = 0; p < nP; p++)
-                if (cnt[s * nP + p] == 1) { const int i = who[s * nP + p]; tidx[count] = i; tg[count] = ue[i].gain; tl[count] = ue[i].lgain; count++; }
-            if (count <= 0) continue;
-            int grantCheck = 0;
-            if (count <= K.nGrantUL) {
-                for (int i = 0; i < count; i++) {
-                    if (K.nonsector) { if (grantCheck < K.nGrantUL) grantCheck++; ue[tidx[i]].msg2 = 1; } // NOMA.c:377-382
-                    else if (grantCheck < K.nGrantUL) { grantCheck++; ue[tidx[i]].msg2 = 1; }             // NOMA.c:245-250
-                }
+        for (int s = 0; s < nsect && status == PRACH_OK; s++) {
+            const bool single = lane < nP && cnt[s * nP + lane] == 1;
+            const int myidx = single ? who[s * nP + lane] : -1;
+            const unsigned long long sm = __ballot(single);
+            const int count = __popcll(sm);
+            if (count == 0) continue;
+            if (count <= K.nGrantUL) { // NOMA.c:245-250 / :377-382: every one of them is granted
+                if (single) ue[myidx].msg2 = 1;
                 continue;
             }
-            for (int i = 0; i < count; i++) // sortUE: bubble sort, strict < (stable), NOMA.c:90-103
-                for (int j = 0; j < count - 1; j++)
-                    if (tg[j + 1] < tg[j]) {
-                        const int ti = tidx[j]; tidx[j] = tidx[j + 1]; tidx[j + 1] = ti;
-                        const double a = tg[j]; tg[j] = tg[j + 1]; tg[j + 1] = a;
-                        const double b = tl[j]; tl[j] = tl[j + 1]; tl[j + 1] = b;
-                    }
-            int pair = 0;
-            for (int i = 0; i < count - 1; i++) {
-                for (int j = 1; j < count; j++) { // (enNoma stays 0: NOMA.c:266,269)
-                    const int rx0 = tidx[i], rx1 = tidx[j];
-                    if (rx0 != -1 && rx1 != -1 && __dsub_rn(__dmul_rn(10.0, tl[j]), __dmul_rn(10.0, tl[i])) > 15.0) {
-                        pair += 2;
-                        tidx[i] = -1; tidx[j] = -1;
-                        if (grantCheck < K.nGrantUL) {
-                            grantCheck++;
-                            if (pos >= slen) { status = PRACH_ERR_STREAM; break; }
-                            const double pd = (double)stream[pos++] / (double)2147483647;
-                            if (pd < 0.3) {
-                                if (K.nonsector) ue[rx0].msg2 = 1; // NOMA.c:413-415
-                                else {
-                                    if (pos >= slen) { status = PRACH_ERR_STREAM; break; }
-                                    const int which = stream[pos++] % 2; // NOMA.c:287-290
-                                    ue[which ? rx1 : rx0].msg2 = 1;
-                                }
-                            } else { ue[rx0].msg2 = 1; ue[rx1].msg2 = 1; }
-                        }
-                        break;
-                    }
+            if (single) { const int q = __popcll(sm & lanemask_lt(lane)); gs_idx[q] = myidx; gs_g[q] = ue[myidx].gain; gs_lg[q] = ue[myidx].lgain; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int uidx = -1, rank = 0;
+            double ug = 0, ulg = 0;
+            bool ambiguous = false;
+            if (lane < count) {
+                uidx = gs_idx[lane]; ug = gs_g[lane]; ulg = gs_lg[lane];
+                for (int j = 0; j < count; j++) {
+                    const double gj = gs_g[j];
+                    rank += (gj < ug || (gj == ug && j < lane)) ? 1 : 0;
+                    if (devact && j != lane && fabs(__dsub_rn(gj, ug)) <= 1e-14 * fmax(gj, ug)) ambiguous = true; // (the libm's gains could order the two the other way)
                 }
-                if (status != PRACH_OK) break;
             }
-            if (status != PRACH_OK) break;
-            if (count - pair > 0)
-                for (int i = 0; i < count; i++)
-                    if (tidx[i] != -1 && grantCheck < K.nGrantUL) { grantCheck++; ue[tidx[i]].msg2 = 1; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < count) { gs_idx[rank] = uidx; gs_lg[rank] = ulg; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int cidx = -1;
+            double clg = 0;
+            if (lane < count) { cidx = gs_idx[lane]; clg = gs_lg[lane]; }
+            unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
+            int grants = 0;
+            bool grantme = false;
+            for (int i = 0; i < count - 1; i++) { // NOMA.c:268-298 (enNoma stays 0: :266,269)
+                if (!((valid >> i) & 1ull)) continue;
+                const double lgi = __shfl(clg, i);
+                const double diff = __dsub_rn(__dmul_rn(10.0, clg), __dmul_rn(10.0, lgi)); // 10*log(high) - 10*log(low)
+                const bool cand = lane > 0 && lane != i && lane < count && ((valid >> lane) & 1ull);
+                if (devact && cand && fabs(__dsub_rn(diff, 15.0)) < 1e-9) ambiguous = true;
+                const unsigned long long mj = __ballot(cand && diff > 15.0);
+                if (!mj) continue;
+                const int j = __ffsll((long long)mj) - 1;
+                valid &= ~((1ull << i) | (1ull << j));
+                if (grants < K.nGrantUL) {
+                    grants++;
+                    if (pos >= slen) { status = PRACH_ERR_STREAM; break; }
+                    const double pd = __ddiv_rn((double)stream[pos++], 2147483647.0);
+                    int decoded = 2; // both
+                    if (pd < 0.3) {
+                        if (K.nonsector) decoded = 0; // rx[0], the weaker UE: NOMA.c:413-415
+                        else {
+                            if (pos >= slen) { status = PRACH_ERR_STREAM; break; }
+                            decoded = stream[pos++] % 2; // NOMA.c:287-290: index into rx[] = {low, high}
+                        }
+                    }
+                    if ((lane == i && (decoded == 2 || decoded == 0)) || (lane == j && (decoded == 2 || decoded == 1))) grantme = true;
+                }
+            }
+            { // leftovers in sorted order while grants remain (NOMA.c:299-307)
+                const bool left = lane < count && ((valid >> lane) & 1ull);
+                const unsigned long long lm = __ballot(left);
+                if (left && __popcll(lm & lanemask_lt(lane)) < K.nGrantUL - grants) grantme = true;
+            }
+            if (grantme && status == PRACH_OK) ue[cidx].msg2 = 1;
+            if (__any(ambiguous) && status == PRACH_OK) status = NOMA_GLIBC_AMBIGUOUS;
         }
-        sh[0] = (int)(pos & 0xffffffffull); sh[1] = (int)(pos >> 32); sh[2] = status;
+        if (tid == 0) { sh[0] = (int)(pos & 0xffffffffull); sh[1] = (int)(pos >> 32); sh[2] = status; }
     }
     __syncthreads();
     pos = ((unsigned long long)(unsigned)sh[1] << 32) | (unsigned)sh[0];
@@ -154,11 +182,12 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, c
 
     // ---- msg2Results in index order (NOMA.c:692-696 -> :449-498): draws at pos + index-ordered prefix ----
     const bool rar_expires = 5 >= K.maxRarWindow; // rarWindow is SET to the literal 5, then compared (NOMA.c:453-455)
-    for (int c0 = 0; c0 < ac && status == PRACH_OK; c0 += WG_THREADS) {
-        const int i = c0 + tid;
+    for (int c0 = 0; c0 < nn && status == PRACH_OK; c0 += WG_THREADS) {
+        const bool in_ = c0 + tid < nn;
+        const int i = in_ ? idx_of(c0 + tid) : 0;
         int need = 0;
         bool act = false;
-        if (i < ac) {
+        if (in_) {
             const NG NUe &u = ue[i];
             act = u.nowBackoff <= 0 && u.txTime == time + 1 && u.active == 1 && u.RA == 0 && u.RaFailed == 0;
             if (act && u.msg2 == 0 && rar_expires) need = (u.msg1ReTx + 1 >= K.maxMsg1ReTx) ? 2 : 1;
@@ -200,11 +229,12 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, c
     for (int k = 0; k < aT && time + k < K.stop && status == PRACH_OK && exit_time < 0; k++) {
         const int tk = time + k;
         int succ_here = 0;
-        for (int c0 = 0; c0 < ac && status == PRACH_OK; c0 += WG_THREADS) {
-            const int i = c0 + tid;
+        for (int c0 = 0; c0 < nn && status == PRACH_OK; c0 += WG_THREADS) {
+            const bool in_ = c0 + tid < nn;
+            const int i = in_ ? idx_of(c0 + tid) : 0;
             int need = 0;
             bool due = false;
-            if (i < ac) {
+            if (in_) {
                 const NG NUe &u = ue[i];
                 due = u.txTime == tk && u.msg2 == 1 && u.active == 2 && u.RaFailed == 0;
                 if (due) need = u.msg3Wait <= 48 ? 1 : 2;
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, c
             int tot;
             const int off = block_excl_scan(need, wtot, tot);
             if (pos + (unsigned long long)tot > slen) { status = PRACH_ERR_STREAM; break; }
-            if (i < ac) {
+            if (in_) {
                 NG NUe &u = ue[i];
                 if (due) {
                     if (u.msg3Wait <= 48) {
@@ -237,11 +267,22 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, c
         // successUEs counts over ALL nUE; a UE beyond activeCheck has not succeeded, so the count over the arrived ones decides
         int tot;
         (void)block_excl_scan(succ_here, wtot, tot);
-        nsucc = tot;
+        nsucc = tot + succ_removed;
         if (nsucc == K.nUE) exit_time = tk;
     }
     __syncthreads();
-    if (tid == 0) {
+    pos_io = pos; status_out = status; exit_time_out = exit_time; nsucc_out = nsucc;
+}
+
+// one access slot per launch: the arrivals of the slot have been activated by the host (prach_noma_activation_stream) before it
+__global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, const int *stream_, SlotCtl *ctl_, const NParams K) {
+    __shared__ int cnt[6 * 64], who[6 * 64], wtot[NW], sh[8], gs_idx[64];
+    __shared__ double gs_g[64], gs_lg[64];
+    NG SlotCtl *const ctl = (NG SlotCtl *)ctl_;
+    unsigned long long pos = ctl->pos;
+    int status = PRACH_OK, exit_time = -1, nsucc = 0;
+    noma_glibc_slot((NG NUe *)ue_, (const NG int *)stream_, K, cnt, who, wtot, sh, gs_idx, gs_g, gs_lg, ctl->time, ctl->activeCheck, nullptr, 0, 0, ctl->stream_len, false, pos, status, exit_time, nsucc);
+    if (threadIdx.x == 0) {
         ctl->pos = pos;
         ctl->nSuccess = nsucc;
         ctl->exit_time = exit_time;
@@ -249,12 +290,106 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, c
     }
 }
 
+// The WHOLE trial in one launch: activeUE (NOMA.c:131-192) runs on the device too.  The arrivals of a slot take their draws from the stream in index
+// order and each takes a data-dependent number of them (two rejection loops), so their stream positions are found by iteration: every arrival
+// assumes a start, runs activeUE from there and reports how many values it took; a block-wide prefix gives the starts these counts imply; until
+// no start moves (the first arrival's start is right from the beginning, so every round fixes at least one more: two or three rounds in practice).
+// Gains come from the device's math library: prach_noma_act.h flags every value inside its error band, the slot's comparisons do the same —
+// either ends the trial with NOMA_GLIBC_AMBIGUOUS and the host runs it again slot by slot with its own libm.
+struct TrialCtl { unsigned long long pos, steps; int nSuccess, time_exit, status, activeCheck; };
+
+__global__ __launch_bounds__(WG_THREADS) void noma_glibc_trial_kernel(NUe *ue_, const int *stream_, const int *sched_, int *live_, TrialCtl *ctl_, const unsigned long long slen,
+                                                                      const float cell_radius, const NParams K) {
+    __shared__ int cnt[6 * 64], who[6 * 64], wtot[NW], sh[8], gs_idx[64];
+    __shared__ double gs_g[64], gs_lg[64];
+    NG NUe *const ue = (NG NUe *)ue_;
+    const NG int *const stream = (const NG int *)stream_;
+    const NG int *const sched = (const NG int *)sched_;
+    NG int *const live = (NG int *)live_; // the arrived UEs that have neither succeeded nor been dropped, ascending (see noma_glibc_slot)
+    const int tid = threadIdx.x, aT = K.aT;
+    unsigned long long pos = 0, steps = 0;
+    int activeCheck = 0, nlive = 0, succ_removed = 0, status = PRACH_OK, nsucc = 0, time_exit = K.stop;
+    for (int s = 0, t = 0; t < K.stop && status == PRACH_OK; s++, t += aT) {
+        const int prevAC = activeCheck;
+        activeCheck = sched[s]; // NOMA.c:675-681
+        for (int c0 = prevAC; c0 < activeCheck && status == PRACH_OK; c0 += WG_THREADS) { // NOMA.c:682-686, 1024 arrivals at a time
+            const int i = c0 + tid;
+            const bool v = i < activeCheck;
+            unsigned long long start = pos + 4ull * (unsigned long long)tid; // (most UEs take four values)
+            ActUe o{0, 0, 0.0, 0.0, false};
+            int used = 0, total = 0;
+            bool oob = false;
+            for (int round = 0;; round++) {
+                used = 0; oob = false;
+                if (v) o = noma_active_ue([&]() -> int {
+                        const unsigned long long q = start + (unsigned long long)used++;
+                        if (q < slen) return stream[q];
+                        oob = true; // (beyond the window: the trial ends with PRACH_ERR_STREAM below; any value that lets the loops end will do)
+                        return 2147483647 / 3;
+                    }, K.nP, cell_radius);
+                int tot;
+                const int excl = block_excl_scan(v ? used : 0, wtot, tot);
+                const unsigned long long ns = pos + (unsigned long long)excl;
+                const int moved = __syncthreads_or(v && ns != start);
+                start = ns;
+                total = tot;
+                if (!moved) break;
+                if (round > 1100) { status = PRACH_ERR_INTERNAL; break; } // (cannot happen: every round fixes at least one more start)
+            }
+            if (__syncthreads_or(v && oob)) status = PRACH_ERR_STREAM;
+            else if (__syncthreads_or(v && o.flag)) status = NOMA_GLIBC_AMBIGUOUS;
+            if (v && status == PRACH_OK) {
+                NG NUe &u = ue[i];
+                u.active = 1; u.preamble = o.pre; u.nTxPreamble = 1; u.txTime = t + 1; u.timer = 0; u.rarWindow = 0; u.msg1ReTx = 0; u.nowBackoff = 0;
+                u.firstTxTime = t + 1; u.sector = o.sec; u.gain = o.gain; u.lgain = o.lgain;
+                live[nlive + (i - prevAC)] = i; // (arrivals join the list in index order, behind everybody who arrived before)
+            }
+            pos += (unsigned long long)total;
+        }
+        nlive += activeCheck - prevAC;
+        __syncthreads(); // the activated records are in memory
+        if (status != PRACH_OK) break;
+        int st = PRACH_OK, ex = -1;
+        noma_glibc_slot(ue, stream, K, cnt, who, wtot, sh, gs_idx, gs_g, gs_lg, t, activeCheck, live, nlive, succ_removed, slen, true, pos, st, ex, nsucc);
+        status = st;
+        steps = (unsigned long long)min(t + aT, K.stop);
+        if (status != PRACH_OK) break;
+        if (ex >= 0) { time_exit = ex; steps = (unsigned long long)ex + 1ull; break; }
+        // the UEs that succeeded or were dropped in this slot leave the list: stable compaction in place, 1024 entries at a time (an entry only ever
+        // moves down, and the barriers of the block-wide prefix separate a block's reads from the writes of the next)
+        {
+            int out = 0;
+            for (int c0 = 0; c0 < nlive; c0 += WG_THREADS) {
+                const bool in_ = c0 + tid < nlive;
+                const int i = in_ ? live[c0 + tid] : 0;
+                int keep = 0, ra = 0;
+                if (in_) { const NG NUe &u = ue[i]; ra = u.RA == 1 ? 1 : 0; keep = (ra || u.RaFailed != 0) ? 0 : 1; }
+                int tot;
+                const int excl = block_excl_scan(keep, wtot, tot);
+                succ_removed += __syncthreads_count(in_ && ra);
+                if (keep) live[out + excl] = i;
+                out += tot;
+            }
+            nlive = out;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        NG TrialCtl *const ctl = (NG TrialCtl *)ctl_;
+        ctl->pos = pos; ctl->steps = steps; ctl->nSuccess = nsucc; ctl->time_exit = time_exit; ctl->status = status; ctl->activeCheck = activeCheck;
+    }
+}
+
 } // namespace
 
 // One NOMA_C trial in the reference's rand() stream.  `hstream`: the host copy of the window [stream_offset, +len) (prach_glibc_stream).
 // Returns PRACH_OK, PRACH_ERR_STREAM (window too small: the caller retries with a larger one) or a device error.
+// device_activation: the whole trial as ONE launch (noma_glibc_trial_kernel: activeUE on the device); returns NOMA_GLIBC_AMBIGUOUS_RC when a value fell inside
+// the device math library's error band — the caller then runs the trial again with device_activation = false (one launch per access slot, the
+// arrivals activated by the host with the reference's libm between them).
 int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *hstream, unsigned long long len, prach_result *res, prach_ue_log *logs,
-                         double *kernel_ms) {
+                         double *kernel_ms, bool device_activation) {
 #define NHIP(expr)                                                                                                            \
     do {                                                                                                                      \
         hipError_t e_ = (expr);                                                                                               \
@@ -270,6 +405,7 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
     NUe *d_ue = nullptr;
     int *d_stream = nullptr;
     SlotCtl *d_ctl = nullptr, *h_ctl = nullptr;
+    int *d_sched = nullptr, *d_live = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<NUe> hue((size_t)nUE);
     std::vector<int32_t> sched((size_t)(maxTime / aT + 2), nUE);
@@ -289,8 +425,22 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
     NHIP(hipEventCreate(&ev1));
     NHIP(hipMemcpyAsync(d_ue, hue.data(), sizeof(NUe) * (size_t)nUE, hipMemcpyHostToDevice, stream));
     NHIP(hipMemcpyAsync(d_stream, hstream, 4 * (size_t)len, hipMemcpyHostToDevice, stream));
+    static_assert(sizeof(TrialCtl) <= sizeof(SlotCtl), "the control block is shared");
     NHIP(hipEventRecord(ev0, stream));
-    for (int s = 0, t = 0; t < stop; s++, t += aT) {
+    if (device_activation) {
+        NHIP(hipMalloc(reinterpret_cast<void **>(&d_sched), 4 * sched.size()));
+        NHIP(hipMemcpyAsync(d_sched, sched.data(), 4 * sched.size(), hipMemcpyHostToDevice, stream));
+        NHIP(hipMalloc(reinterpret_cast<void **>(&d_live), 4 * (size_t)nUE + 64));
+        hipLaunchKernelGGL(noma_glibc_trial_kernel, dim3(1), dim3(WG_THREADS), 0, stream, d_ue, d_stream, d_sched, d_live, reinterpret_cast<TrialCtl *>(d_ctl), len, c.cellRadius, K);
+        NHIP(hipGetLastError());
+        NHIP(hipMemcpyAsync(h_ctl, d_ctl, sizeof(SlotCtl), hipMemcpyDeviceToHost, stream));
+        NHIP(hipStreamSynchronize(stream));
+        const TrialCtl tc = *reinterpret_cast<const TrialCtl *>(h_ctl);
+        if (tc.status == NOMA_GLIBC_AMBIGUOUS) { rc = NOMA_GLIBC_AMBIGUOUS_RC; goto done; }
+        if (tc.status != PRACH_OK) { rc = tc.status; goto done; }
+        pos = tc.pos; steps = tc.steps; nSuccess = tc.nSuccess; time_exit = tc.time_exit; activeCheck = tc.activeCheck;
+    }
+    else for (int s = 0, t = 0; t < stop; s++, t += aT) {
         // NOMA.c:675-686: this access slot's arrivals, activated on the host in stream order (index order)
         const int prevAC = activeCheck;
         activeCheck = sched[s];
@@ -358,6 +508,8 @@ done:
     if (d_ue) (void)hipFree(d_ue);
     if (d_stream) (void)hipFree(d_stream);
     if (d_ctl) (void)hipFree(d_ctl);
+    if (d_sched) (void)hipFree(d_sched);
+    if (d_live) (void)hipFree(d_live);
     if (h_ctl) (void)hipHostFree(h_ctl);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);

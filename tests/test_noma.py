@@ -342,3 +342,14 @@ def test_gpu_noma_glibc_equals_oracle(pkg, ob, engine):
         b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
         diff = np.where((a != b).any(axis=1))[0]
         assert diff.size == 0, (nUE, seed, kw, diff[:5], a[diff[:3]], b[diff[:3]])
+        # the same trial slot by slot with the arrivals activated by the host (the form a trial falls back to when the single-launch kernel finds a
+        # value inside the device libm's error band) — also reached through the test hook
+        for key in ("noma_host_activation", "noma_ambiguity_test"):
+            engine.set(key, 1)
+            try:
+                (res2,), (logs2,) = engine.run_trials([cfg], want_logs=True)
+                assert engine.timing().fallback_trials == (1 if key == "noma_ambiguity_test" else 0)
+            finally:
+                engine.set(key, 0)
+            assert (res2.nSuccessUE, res2.sumTimer, res2.draws, res2.time_exit, res2.steps) == (res.nSuccessUE, res.sumTimer, res.draws, res.time_exit, res.steps)
+            assert bytes(logs2) == bytes(logs)
