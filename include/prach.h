@@ -180,7 +180,8 @@ const char *prach_strerror(int status);
  * math library and the host's could change a float rounding, the rejection test or the draw count.  Engine option
  * "noma_host_activation" = 1 builds the whole table with the functions here instead (the round-1/2 behaviour).
  * This table form is the Philox mode's (draw k of UE i is independent of every other UE).  In glibc mode the rejection loops make
- * every stream position data dependent: there the engine activates arrivals one by one with prach_noma_activation_stream below. */
+ * every stream position data dependent: there the whole trial is one launch with activeUE inside it (same error bands); a trial that hits
+ * a band is run again slot by slot, its arrivals activated one by one with prach_noma_activation_stream below. */
 int prach_noma_activation_table(const prach_cfg *cfg, int32_t *preamble0, int32_t *sector, double *gain, double *lgain,
                                 uint32_t *ndraws);
 /* the same for the UEs [lo, hi) only (outputs indexed from lo): ranges are independent, the engine builds them on all host cores */

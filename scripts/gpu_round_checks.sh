@@ -15,3 +15,4 @@ python3 tests/tools/gpu_fuzz_batch.py 68 10 big 2>&1 | grep -v "^\[prach\]" | ta
 python3 tests/tools/gpu_fuzz_batch.py 70 60 small glibc 2>&1 | grep -v "^\[prach\]" | tail -1
 PRACH_LIB=$GRAFT_REPO_ROOT/5g-nr-randomaccess_amd/libprach_hip_tinyq.so python3 tests/tools/gpu_fuzz_batch.py 77 30 small glibc 2>&1 | grep -v "^\[prach\]" | tail -1
 python3 tests/tools/gpu_fuzz_noma.py 69 60 2>&1 | grep -v "^\[prach\]" | tail -1
+python3 tests/tools/gpu_fuzz_noma.py 78 60 glibc 2>&1 | grep -v "^\[prach\]" | tail -1
