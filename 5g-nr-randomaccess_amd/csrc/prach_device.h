@@ -132,8 +132,10 @@ constexpr int NOMA_ACT_FLAG_CAP = 8192;
 constexpr int NOMA_AMBIGUOUS = 77; // DevResult::hard_error: a gain comparison of the resolver fell inside the error band (the trial is rerun with the host-built table)
 hipError_t launch_noma_activation(const TrialDev *params, int ntrials, int maxUE, unsigned *flags, hipStream_t stream);
 // NOMA_C in the reference's own rand() stream (prach_noma_glibc.hip): one trial, host-activated arrivals + one device step per access slot
-constexpr int NOMA_GLIBC_AMBIGUOUS_RC = -1077; // run_noma_glibc_trial(device_activation): a value inside the device libm's error band — run it again on the host-activated path
+constexpr int NOMA_GLIBC_AMBIGUOUS_RC = -1077; // run_noma_glibc_batch: a value inside the device libm's error band — run that trial on the host-activated path
 int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *hstream, unsigned long long len, prach_result *res, prach_ue_log *logs,
-                         double *kernel_ms, bool device_activation);
+                         double *kernel_ms);
+int run_noma_glibc_batch(hipStream_t stream, const prach_cfg *const *cfgs, int n, const unsigned long long *lens, prach_result *const *res, prach_ue_log *const *logs,
+                         double *kernel_ms, int *rcs);
 
 } // namespace prach

@@ -607,30 +607,59 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
     // NOMA.c in the reference's OWN rand() stream: activeUE's rejection loops make every stream position data dependent and its libm
     // calls must be the reference's, so the arrivals are activated on the host between device steps (prach_noma_glibc.hip): one trial
     // at a time, one launch per access slot — the bit-exact-vs-the-reference's-files mode, not the throughput mode
-    for (int k = 0; k < n; k++) {
-        if (cfgs[k].variant != PRACH_VARIANT_NOMA_C || cfgs[k].rng_mode != PRACH_RNG_GLIBC) continue;
-        int rc = PRACH_ERR_STREAM;
-        for (int attempt = 0; attempt < 4 && rc == PRACH_ERR_STREAM; attempt++) { // (48, 192, 768, 3072 values per UE: 1.2 GB at nUE = 100 000 at most, then PRACH_ERR_STREAM)
-            const unsigned long long len = ((unsigned long long)cfgs[k].nUE * 48ull + (1ull << 18)) << (2 * attempt);
-            std::vector<int32_t> hs((size_t)len);
-            prach_glibc_stream((uint32_t)cfgs[k].seed, cfgs[k].stream_offset, len, hs.data());
-            // one launch for the whole trial, activeUE on the device; a value inside the device math library's error band (prach_noma_act.h: ~7 % of
-            // the nUE = 100 000 trials) sends the trial to the slot-by-slot form, whose arrivals the host activates with the reference's libm
-            const bool devact = !e->opt_noma_host_activation;
-            if (devact && e->opt_noma_ambiguity_test) rc = NOMA_GLIBC_AMBIGUOUS_RC; // (test hook: as if the kernel had found a value inside the band)
-            else {
-                rc = run_noma_glibc_trial(e->stream, cfgs[k], hs.data(), len, &results[k], ue_logs ? ue_logs[k] : nullptr, &kernel_ms, devact);
+    {
+        std::vector<int> todo;
+        for (int k = 0; k < n; k++)
+            if (cfgs[k].variant == PRACH_VARIANT_NOMA_C && cfgs[k].rng_mode == PRACH_RNG_GLIBC) todo.push_back(k);
+        // window of trial k at retry level a: 48, 192, 768, 3072 values per UE (1.2 GB at nUE = 100 000 at most, then PRACH_ERR_STREAM)
+        auto window = [&](int k, int a) { return ((unsigned long long)cfgs[k].nUE * 48ull + (1ull << 18)) << (2 * a); };
+        // slot by slot, the arrivals activated by the host with the reference's libm (prach_noma_glibc.hip): the exact form a trial falls back to
+        auto host_form = [&](int k) -> int {
+            int rc = PRACH_ERR_STREAM;
+            for (int attempt = 0; attempt < 4 && rc == PRACH_ERR_STREAM; attempt++) {
+                const unsigned long long len = window(k, attempt);
+                std::vector<int32_t> hs((size_t)len);
+                prach_glibc_stream((uint32_t)cfgs[k].seed, cfgs[k].stream_offset, len, hs.data());
+                rc = run_noma_glibc_trial(e->stream, cfgs[k], hs.data(), len, &results[k], ue_logs ? ue_logs[k] : nullptr, &kernel_ms);
                 e->last.launches++;
             }
-            if (rc == NOMA_GLIBC_AMBIGUOUS_RC) {
+            return rc;
+        };
+        if (e->opt_noma_host_activation) {
+            for (int k : todo) { int rc = host_form(k); if (rc != PRACH_OK) return rc; }
+            todo.clear();
+        }
+        // the single-launch form: every trial of the call (the seeds of a sweep point) side by side, one workgroup each, activeUE on the device; a value
+        // inside the device math library's error band (prach_noma_act.h: a few percent of the trials) sends that trial to the host form
+        for (int attempt = 0; !todo.empty(); attempt++) {
+            if (attempt >= 4) return PRACH_ERR_STREAM;
+            const int m = (int)todo.size();
+            std::vector<const prach_cfg *> pc(m);
+            std::vector<unsigned long long> lens(m);
+            std::vector<prach_result *> pr(m);
+            std::vector<prach_ue_log *> pl(m);
+            std::vector<int> rcs(m, PRACH_ERR_INTERNAL);
+            for (int j = 0; j < m; j++) { pc[j] = &cfgs[todo[j]]; lens[j] = window(todo[j], attempt); pr[j] = &results[todo[j]]; pl[j] = ue_logs ? ue_logs[todo[j]] : nullptr; }
+            if (e->opt_noma_ambiguity_test) std::fill(rcs.begin(), rcs.end(), NOMA_GLIBC_AMBIGUOUS_RC); // (test hook: as if the kernel had found a value inside the band)
+            else {
+                int rc = run_noma_glibc_batch(e->stream, pc.data(), m, lens.data(), pr.data(), pl.data(), &kernel_ms, rcs.data());
+                e->last.launches++;
+                if (rc != PRACH_OK) return rc;
+            }
+            std::vector<int> again;
+            for (int j = 0; j < m; j++) {
+                const int k = todo[j];
+                if (rcs[j] == PRACH_OK) continue;
+                if (rcs[j] == PRACH_ERR_STREAM) { again.push_back(k); continue; }
+                if (rcs[j] != NOMA_GLIBC_AMBIGUOUS_RC) return rcs[j];
                 e->noma_ambiguous++;
                 e->last.fallback_trials++;
                 if (std::getenv("PRACH_VERBOSE")) std::fprintf(stderr, "[prach] NOMA.c trial nUE=%d in the reference's stream: a value inside the device libm's error band, rerun with host-side activation\n", cfgs[k].nUE);
-                rc = run_noma_glibc_trial(e->stream, cfgs[k], hs.data(), len, &results[k], ue_logs ? ue_logs[k] : nullptr, &kernel_ms, false);
-                e->last.launches++;
+                int rc = host_form(k);
+                if (rc != PRACH_OK) return rc;
             }
+            todo.swap(again);
         }
-        if (rc != PRACH_OK) return rc;
     }
     { // NOMA.c variant (Philox): its own kernel, G workgroups per trial like the production kernel
         std::vector<int> idx;

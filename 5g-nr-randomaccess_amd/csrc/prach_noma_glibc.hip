@@ -297,16 +297,29 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, c
 // Gains come from the device's math library: prach_noma_act.h flags every value inside its error band, the slot's comparisons do the same —
 // either ends the trial with NOMA_GLIBC_AMBIGUOUS and the host runs it again slot by slot with its own libm.
 struct TrialCtl { unsigned long long pos, steps; int nSuccess, time_exit, status, activeCheck; };
+struct TrialArgs { NUe *ue; const int *stream; const int *sched; int *live; TrialCtl *ctl; unsigned long long slen; float cell_radius; int pad; NParams K; };
 
-__global__ __launch_bounds__(WG_THREADS) void noma_glibc_trial_kernel(NUe *ue_, const int *stream_, const int *sched_, int *live_, TrialCtl *ctl_, const unsigned long long slen,
-                                                                      const float cell_radius, const NParams K) {
+// (one workgroup per trial: the trials of a call — the seeds of one sweep point — run side by side)
+__global__ __launch_bounds__(WG_THREADS) void noma_glibc_trial_kernel(const TrialArgs *__restrict__ args) {
     __shared__ int cnt[6 * 64], who[6 * 64], wtot[NW], sh[8], gs_idx[64];
     __shared__ double gs_g[64], gs_lg[64];
-    NG NUe *const ue = (NG NUe *)ue_;
-    const NG int *const stream = (const NG int *)stream_;
-    const NG int *const sched = (const NG int *)sched_;
-    NG int *const live = (NG int *)live_; // the arrived UEs that have neither succeeded nor been dropped, ascending (see noma_glibc_slot)
+    const TrialArgs &A = args[blockIdx.x];
+    const NParams K = A.K;
+    const unsigned long long slen = A.slen;
+    const float cell_radius = A.cell_radius;
+    TrialCtl *const ctl_ = A.ctl;
+    NG NUe *const ue = (NG NUe *)A.ue;
+    const NG int *const stream = (const NG int *)A.stream;
+    const NG int *const sched = (const NG int *)A.sched;
+    NG int *const live = (NG int *)A.live; // the arrived UEs that have neither succeeded nor been dropped, ascending (see noma_glibc_slot)
     const int tid = threadIdx.x, aT = K.aT;
+    for (int i = tid; i < K.nUE; i += WG_THREADS) { // calloc + initUserInfo (NOMA.c:651-655): everything 0, sector -1
+        NG int *const p = (NG int *)&ue[i];
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(NUe) / 4); k++) p[k] = 0;
+        ue[i].sector = -1;
+    }
+    __syncthreads();
     unsigned long long pos = 0, steps = 0;
     int activeCheck = 0, nlive = 0, succ_removed = 0, status = PRACH_OK, nsucc = 0, time_exit = K.stop;
     for (int s = 0, t = 0; t < K.stop && status == PRACH_OK; s++, t += aT) {
@@ -383,13 +396,46 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_trial_kernel(NUe *ue_, 
 
 } // namespace
 
+// saveResult (NOMA.c:618-625) and the logged fields from the final UE records
+static void noma_glibc_finish(const prach_cfg &c, const NUe *hue, unsigned long long pos, int nSuccess, int time_exit, unsigned long long steps, int activeCheck,
+                              int32_t nAccess, prach_result *res, prach_ue_log *logs) {
+    const int nUE = c.nUE;
+    long long delay = 0;
+    int nTxP = 0, failed = 0;
+    for (int i = 0; i < nUE; i++) {
+        const NUe &u = hue[i];
+        if (u.RA == 1) { delay += u.timer; nTxP += u.nTxPreamble; }
+        if (u.RaFailed) failed++;
+        if (logs) { // (the field mapping of prach_noma.hip's dump)
+            prach_ue_log &o = logs[i];
+            o.idx = i; o.timer = u.timer; o.active = u.active; o.txTime = u.txTime; o.firstTxTime = u.firstTxTime; o.secondTxTime = u.secondTxTime;
+            o.nowBackoff = u.nowBackoff; o.preamble = u.preamble; o.preambleChange = u.sector; o.rarWindow = u.rarWindow; o.maxRarCounter = u.msg1ReTx;
+            o.preambleTxCounter = u.nTxPreamble; o.msg2Flag = u.msg2; o.connectionRequest = u.msg3Wait; o.msg4Flag = u.RA;
+            o.failCount = u.RaFailed | (u.msg3Faile << 16);
+        }
+    }
+    std::memset(res, 0, sizeof(*res));
+    res->status = PRACH_OK;
+    res->time_exit = time_exit;
+    res->maxTime = 10000;
+    res->nSuccessUE = nSuccess;
+    res->failedUEs = nUE - nSuccess;
+    res->preambleTxCount = nTxP;
+    res->failCounts = failed;
+    res->activeCheck = activeCheck;
+    res->nAccessUE = nAccess;
+    res->finalSuccessUEs = nSuccess;
+    res->sumTimer = delay;
+    res->totalDelay = (float)delay;
+    res->draws = pos;
+    res->steps = steps;
+}
+
 // One NOMA_C trial in the reference's rand() stream.  `hstream`: the host copy of the window [stream_offset, +len) (prach_glibc_stream).
 // Returns PRACH_OK, PRACH_ERR_STREAM (window too small: the caller retries with a larger one) or a device error.
-// device_activation: the whole trial as ONE launch (noma_glibc_trial_kernel: activeUE on the device); returns NOMA_GLIBC_AMBIGUOUS_RC when a value fell inside
-// the device math library's error band — the caller then runs the trial again with device_activation = false (one launch per access slot, the
-// arrivals activated by the host with the reference's libm between them).
+// This is the slot-by-slot form (the arrivals activated by the host between the launches); run_noma_glibc_batch below is the single-launch form.
 int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *hstream, unsigned long long len, prach_result *res, prach_ue_log *logs,
-                         double *kernel_ms, bool device_activation) {
+                         double *kernel_ms) {
 #define NHIP(expr)                                                                                                            \
     do {                                                                                                                      \
         hipError_t e_ = (expr);                                                                                               \
@@ -405,7 +451,6 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
     NUe *d_ue = nullptr;
     int *d_stream = nullptr;
     SlotCtl *d_ctl = nullptr, *h_ctl = nullptr;
-    int *d_sched = nullptr, *d_live = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<NUe> hue((size_t)nUE);
     std::vector<int32_t> sched((size_t)(maxTime / aT + 2), nUE);
@@ -425,22 +470,8 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
     NHIP(hipEventCreate(&ev1));
     NHIP(hipMemcpyAsync(d_ue, hue.data(), sizeof(NUe) * (size_t)nUE, hipMemcpyHostToDevice, stream));
     NHIP(hipMemcpyAsync(d_stream, hstream, 4 * (size_t)len, hipMemcpyHostToDevice, stream));
-    static_assert(sizeof(TrialCtl) <= sizeof(SlotCtl), "the control block is shared");
     NHIP(hipEventRecord(ev0, stream));
-    if (device_activation) {
-        NHIP(hipMalloc(reinterpret_cast<void **>(&d_sched), 4 * sched.size()));
-        NHIP(hipMemcpyAsync(d_sched, sched.data(), 4 * sched.size(), hipMemcpyHostToDevice, stream));
-        NHIP(hipMalloc(reinterpret_cast<void **>(&d_live), 4 * (size_t)nUE + 64));
-        hipLaunchKernelGGL(noma_glibc_trial_kernel, dim3(1), dim3(WG_THREADS), 0, stream, d_ue, d_stream, d_sched, d_live, reinterpret_cast<TrialCtl *>(d_ctl), len, c.cellRadius, K);
-        NHIP(hipGetLastError());
-        NHIP(hipMemcpyAsync(h_ctl, d_ctl, sizeof(SlotCtl), hipMemcpyDeviceToHost, stream));
-        NHIP(hipStreamSynchronize(stream));
-        const TrialCtl tc = *reinterpret_cast<const TrialCtl *>(h_ctl);
-        if (tc.status == NOMA_GLIBC_AMBIGUOUS) { rc = NOMA_GLIBC_AMBIGUOUS_RC; goto done; }
-        if (tc.status != PRACH_OK) { rc = tc.status; goto done; }
-        pos = tc.pos; steps = tc.steps; nSuccess = tc.nSuccess; time_exit = tc.time_exit; activeCheck = tc.activeCheck;
-    }
-    else for (int s = 0, t = 0; t < stop; s++, t += aT) {
+    for (int s = 0, t = 0; t < stop; s++, t += aT) {
         // NOMA.c:675-686: this access slot's arrivals, activated on the host in stream order (index order)
         const int prevAC = activeCheck;
         activeCheck = sched[s];
@@ -474,47 +505,108 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
         float ms = 0;
         NHIP(hipEventElapsedTime(&ms, ev0, ev1));
         if (kernel_ms) *kernel_ms += ms;
-        long long delay = 0;
-        int nTxP = 0, failed = 0;
-        for (int i = 0; i < nUE; i++) { // saveResult, NOMA.c:618-625
-            const NUe &u = hue[i];
-            if (u.RA == 1) { delay += u.timer; nTxP += u.nTxPreamble; }
-            if (u.RaFailed) failed++;
-            if (logs) { // (the field mapping of prach_noma.hip's dump)
-                prach_ue_log &o = logs[i];
-                o.idx = i; o.timer = u.timer; o.active = u.active; o.txTime = u.txTime; o.firstTxTime = u.firstTxTime; o.secondTxTime = u.secondTxTime;
-                o.nowBackoff = u.nowBackoff; o.preamble = u.preamble; o.preambleChange = u.sector; o.rarWindow = u.rarWindow; o.maxRarCounter = u.msg1ReTx;
-                o.preambleTxCounter = u.nTxPreamble; o.msg2Flag = u.msg2; o.connectionRequest = u.msg3Wait; o.msg4Flag = u.RA;
-                o.failCount = u.RaFailed | (u.msg3Faile << 16);
-            }
-        }
-        std::memset(res, 0, sizeof(*res));
-        res->status = PRACH_OK;
-        res->time_exit = time_exit;
-        res->maxTime = maxTime;
-        res->nSuccessUE = nSuccess;
-        res->failedUEs = nUE - nSuccess;
-        res->preambleTxCount = nTxP;
-        res->failCounts = failed;
-        res->activeCheck = activeCheck;
-        res->nAccessUE = nAccess;
-        res->finalSuccessUEs = nSuccess;
-        res->sumTimer = delay;
-        res->totalDelay = (float)delay;
-        res->draws = pos;
-        res->steps = steps;
+        noma_glibc_finish(c, hue.data(), pos, nSuccess, time_exit, steps, activeCheck, nAccess, res, logs);
     }
 done:
     if (d_ue) (void)hipFree(d_ue);
     if (d_stream) (void)hipFree(d_stream);
     if (d_ctl) (void)hipFree(d_ctl);
-    if (d_sched) (void)hipFree(d_sched);
-    if (d_live) (void)hipFree(d_live);
     if (h_ctl) (void)hipHostFree(h_ctl);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     return rc;
 #undef NHIP
+}
+
+// The single-launch form for the NOMA_C trials of a call (the seeds of one sweep point): one workgroup per trial in ONE launch, the stream windows
+// [stream_offset, + lens[j]) generated on the device before it.  rcs[j]: PRACH_OK (res[j] / logs[j] filled), PRACH_ERR_STREAM (window too small),
+// NOMA_GLIBC_AMBIGUOUS_RC (a value inside the device math library's error band: run that trial slot by slot, run_noma_glibc_trial) or a device error.
+int run_noma_glibc_batch(hipStream_t stream, const prach_cfg *const *cfgs, int n, const unsigned long long *lens, prach_result *const *res, prach_ue_log *const *logs,
+                         double *kernel_ms, int *rcs) {
+#define BHIP(expr)                                                                                                            \
+    do {                                                                                                                      \
+        hipError_t e_ = (expr);                                                                                               \
+        if (e_ != hipSuccess) {                                                                                               \
+            std::fprintf(stderr, "[prach] HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, __LINE__, hipGetErrorString(e_)); \
+            rc = PRACH_ERR_DEVICE;                                                                                            \
+            goto done;                                                                                                        \
+        }                                                                                                                     \
+    } while (0)
+    int rc = PRACH_OK;
+    const int maxTime = 10000;
+    char *dbuf = nullptr, *hbuf = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct Off { size_t seeds, sched, ue, stream, live; size_t nsched, nchunks; int32_t nAccess; };
+    std::vector<Off> off((size_t)n);
+    std::vector<NUe> hue;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    // staged prefix (one copy): argument blocks, control blocks (zeroed), stream seeds, arrival tables; then the per-trial arrays
+    size_t o = up(sizeof(TrialArgs) * (size_t)n);
+    const size_t octl = o; o = up(o + sizeof(TrialCtl) * (size_t)n);
+    for (int j = 0; j < n; j++) {
+        const prach_cfg &c = *cfgs[j];
+        off[j].nsched = (size_t)(maxTime / c.accessTime + 2);
+        off[j].nchunks = (size_t)((lens[j] + STREAM_CHUNK - 1) / STREAM_CHUNK);
+        off[j].seeds = o; o = up(o + 4 * 31 * (off[j].nchunks + 1));
+        off[j].sched = o; o = up(o + 4 * off[j].nsched);
+    }
+    const size_t staged = o;
+    for (int j = 0; j < n; j++) {
+        const prach_cfg &c = *cfgs[j];
+        off[j].ue = o; o = up(o + sizeof(NUe) * (size_t)c.nUE);
+        off[j].stream = o; o = up(o + 4 * (size_t)(lens[j] + 2));
+        off[j].live = o; o = up(o + 4 * (size_t)c.nUE + 64);
+    }
+    BHIP(hipMalloc(reinterpret_cast<void **>(&dbuf), o));
+    BHIP(hipHostMalloc(reinterpret_cast<void **>(&hbuf), staged, hipHostMallocDefault));
+    BHIP(hipEventCreate(&ev0));
+    BHIP(hipEventCreate(&ev1));
+    std::memset(hbuf, 0, staged);
+    for (int j = 0; j < n; j++) {
+        const prach_cfg &c = *cfgs[j];
+        const int stop = (c.max_steps > 0 && c.max_steps < maxTime) ? c.max_steps : maxTime;
+        int32_t *sched = reinterpret_cast<int32_t *>(hbuf + off[j].sched);
+        for (size_t q = 0; q < off[j].nsched; q++) sched[q] = c.nUE;
+        prach_arrival_schedule(&c, sched, (int)off[j].nsched, &off[j].nAccess);
+        prach_internal_glibc_seeds((uint32_t)c.seed, c.stream_offset, off[j].nchunks, STREAM_CHUNK, reinterpret_cast<uint32_t *>(hbuf + off[j].seeds));
+        TrialArgs &A = reinterpret_cast<TrialArgs *>(hbuf)[j];
+        A.ue = reinterpret_cast<NUe *>(dbuf + off[j].ue); A.stream = reinterpret_cast<const int *>(dbuf + off[j].stream);
+        A.sched = reinterpret_cast<const int *>(dbuf + off[j].sched); A.live = reinterpret_cast<int *>(dbuf + off[j].live);
+        A.ctl = reinterpret_cast<TrialCtl *>(dbuf + octl) + j; A.slen = lens[j]; A.cell_radius = c.cellRadius; A.pad = 0;
+        A.K = NParams{c.nUE, c.nPreamble, c.backoff, c.nGrantUL, c.maxRarWindow, c.maxMsg2TxCount, c.accessTime, stop, (c.flags & PRACH_FLAG_NOMA_NONSECTOR) ? 1 : 0};
+        rcs[j] = PRACH_ERR_INTERNAL;
+    }
+    BHIP(hipMemcpyAsync(dbuf, hbuf, staged, hipMemcpyHostToDevice, stream));
+    BHIP(hipEventRecord(ev0, stream));
+    for (int j = 0; j < n; j++)
+        BHIP(launch_glibc_stream(reinterpret_cast<const unsigned *>(dbuf + off[j].seeds), reinterpret_cast<int *>(dbuf + off[j].stream), lens[j], stream));
+    hipLaunchKernelGGL(noma_glibc_trial_kernel, dim3((unsigned)n), dim3(WG_THREADS), 0, stream, reinterpret_cast<const TrialArgs *>(dbuf));
+    BHIP(hipGetLastError());
+    BHIP(hipEventRecord(ev1, stream));
+    BHIP(hipMemcpyAsync(hbuf + octl, dbuf + octl, sizeof(TrialCtl) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    BHIP(hipStreamSynchronize(stream));
+    {
+        float ms = 0;
+        BHIP(hipEventElapsedTime(&ms, ev0, ev1));
+        if (kernel_ms) *kernel_ms += ms;
+    }
+    for (int j = 0; j < n; j++) {
+        const prach_cfg &c = *cfgs[j];
+        const TrialCtl tc = reinterpret_cast<const TrialCtl *>(hbuf + octl)[j];
+        if (tc.status == NOMA_GLIBC_AMBIGUOUS) { rcs[j] = NOMA_GLIBC_AMBIGUOUS_RC; continue; }
+        if (tc.status != PRACH_OK) { rcs[j] = tc.status; continue; }
+        hue.resize((size_t)c.nUE);
+        BHIP(hipMemcpy(hue.data(), dbuf + off[j].ue, sizeof(NUe) * (size_t)c.nUE, hipMemcpyDeviceToHost));
+        noma_glibc_finish(c, hue.data(), tc.pos, tc.nSuccess, tc.time_exit, tc.steps, tc.activeCheck, off[j].nAccess, res[j], logs ? logs[j] : nullptr);
+        rcs[j] = PRACH_OK;
+    }
+done:
+    if (dbuf) (void)hipFree(dbuf);
+    if (hbuf) (void)hipHostFree(hbuf);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    return rc;
+#undef BHIP
 }
 
 } // namespace prach
