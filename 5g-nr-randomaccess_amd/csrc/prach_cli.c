@@ -9,8 +9,8 @@
  *
  * `--program noma` runs NOMA.c's loop instead (NOMA.c:644-717: 10 seeds by default, one result line per
  * (seed, nUE) on stdout and appended to TestResults/Sector_{nUE}_Result.txt, "Done" per seed); that
- * variant draws from Philox by default; `--rng glibc` runs it in the reference's own rand() stream (the arrivals of every access
- * slot are then activated on the host between device steps: prach_noma_glibc.hip), chained over the sweep of a seed like NOMA.c:644-647.
+ * variant draws from Philox by default; `--rng glibc` runs it in the reference's own rand() stream (prach_noma_glibc.hip: one launch per
+ * sweep point, the seeds side by side), chained over the sweep of a seed like NOMA.c:644-647.
  *
  * Extensions (not in the reference): --program beta|withnoma|noma, --rng glibc|philox, --nue N,
  * --sweep LO:HI:STEP, --out DIR, --logs 0|1, --device N, --csv FILE (--program beta: the results.csv of
