@@ -507,6 +507,16 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
         slots = sum(c.nUE * ((r_.steps + 4) // 5) for c, r_ in zip(cfgs, rs))
         extras["noma_c_experiment_batched"] = {"trials": len(cfgs), "kernel_updates_per_s": upd / (tmb.kernel_ms * 1e-3), "wall_updates_per_s": upd / wall,
                                                "activation": "device (noma_activation_kernel, inside kernel_ms)", "ues_recomputed_on_host": tmb.noma_host_ues, "updates": upd, "bad": sum(r_.status != 0 for r_ in rs), "roofline": noma_roofline(upd, slots, tmb.kernel_ms, tmb)}
+        # (4c) NOMA.c in ITS OWN rand() stream (the parity mode of config 4): the ten seeds of the sweep's last point, one launch (noma_glibc_trial_kernel)
+        cfgs = [pkg.make_cfg(args.nue, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_GLIBC, seed=s) for s in range(10)]
+        t1 = time.perf_counter()
+        rs, _ = eng.run_trials(cfgs)
+        wall = time.perf_counter() - t1
+        tmg2 = eng.timing()
+        upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
+        extras["noma_c_reference_stream_10_seeds"] = {"trials": len(cfgs), "kernel_updates_per_s": upd / (tmg2.kernel_ms * 1e-3), "wall_updates_per_s": upd / wall, "kernel_ms": tmg2.kernel_ms,
+                                                      "launches": tmg2.launches, "rerun_with_host_activation": tmg2.fallback_trials, "bad": sum(r_.status != 0 for r_ in rs),
+                                                      "nSuccessUE_seed0": rs[0].nSuccessUE, "reference_nSuccessUE_seed0_at_its_own_stream_offset": "tests/golden/noma_c.json (the chained run is test_gpu_noma_glibc_reproduces_reference_lines)"}
         out["extras"] = extras
     if world == 1 and not args.no_cpu:
         from oracle import binding as ob
