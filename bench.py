@@ -433,7 +433,7 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
         # (1b) the reference's stream with many seeds in flight: what `prach_sim -t 100` issues for the sweep's last point (the ten points of a seed are
         # chained through its rand() stream, so a call holds one point of every seed): 100 seeds x nUE = 100 000, Beta.c, one workgroup per trial
         cfgs = [pkg.make_cfg(args.nue, variant=pkg.VARIANT_BETA_C, rng_mode=pkg.RNG_GLIBC, seed=s) for s in range(100)]
-        eng.run_trials(cfgs[:4])  # (arena / code object warm-up)
+        eng.run_trials([pkg.make_cfg(args.nue, variant=pkg.VARIANT_BETA_C, rng_mode=pkg.RNG_GLIBC, seed=s, max_steps=5) for s in range(100)])  # (the call's arena — a one-time hipMalloc of several GB — and the code object)
         t1 = time.perf_counter()
         rs, _ = eng.run_trials(cfgs)
         wall = time.perf_counter() - t1
