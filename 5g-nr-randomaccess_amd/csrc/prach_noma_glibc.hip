@@ -7,11 +7,12 @@
 // reference's order).  Two forms:
 //   * noma_glibc_trial_kernel (round 3, the default): the WHOLE trial in ONE launch.  activeUE runs on the device (prach_noma_act.h; the arrivals'
 //     stream positions by iteration), the passes run over a list of the UEs that are still alive (a band of a few thousand at nUE = 100 000),
-//     the grouping is one wavefront's rank sort + ballot pairing.  141 ms for nUE = 100 000 (round 2: 1.5 s).  The device's cos / sin / log are not
+//     the grouping is one wavefront's rank sort + ballot pairing.  141 ms for nUE = 100 000 (round 2: 1.5 s); the trials of a call side by side.  The device's cos / sin / log are not
 //     the host libm's to the last bit: a value inside the error band (a float rounding boundary, the rejection threshold, two gains too
 //     close to order) ends the launch with NOMA_GLIBC_AMBIGUOUS (a few percent of the trials) and the trial is run again in the other form:
 //   * noma_glibc_slot_kernel: one launch per access slot, the slot's arrivals activated on the HOST between two launches with the libm the
-//     reference links (prach_noma_activation_stream) — bit-identical by construction, 2000 launches and host round trips per trial.
+//     reference links (prach_noma_activation_stream) — bit-identical by construction, 2000 launches and host round trips per trial; with the same
+//     list of live UEs (kept on the device from launch to launch) 148 ms at nUE = 100 000, one trial at a time.
 // This is the bit-exact-vs-the-reference's-own-files mode of config 4, not the throughput mode (Philox, prach_noma.hip).  Reference:
 // NOMA.c:131-192 (activeUE), :194-324 / :325-447 (grouping), :449-498 (msg2Results), :499-546 (resourceRequestAllocation), :665-711 (the time step).
 #include "prach_device.h"
@@ -274,19 +275,52 @@ __device__ __forceinline__ void noma_glibc_slot(NG NUe *const ue, const NG int *
     pos_io = pos; status_out = status; exit_time_out = exit_time; nsucc_out = nsucc;
 }
 
+// The UEs that succeeded or were dropped in this slot leave the list of live UEs: stable compaction in place, 1024 entries at a time (an entry only ever
+// moves down, and the barriers of the block-wide prefix separate a block's reads from the writes of the next).  Returns the new length.
+__device__ __forceinline__ int noma_live_compact(NG NUe *const ue, NG int *const live, const int nlive, int *wtot, int &succ_removed) {
+    const int tid = threadIdx.x;
+    int out = 0;
+    for (int c0 = 0; c0 < nlive; c0 += WG_THREADS) {
+        const bool in_ = c0 + tid < nlive;
+        const int i = in_ ? live[c0 + tid] : 0;
+        int keep = 0, ra = 0;
+        if (in_) { const NG NUe &u = ue[i]; ra = u.RA == 1 ? 1 : 0; keep = (ra || u.RaFailed != 0) ? 0 : 1; }
+        int tot;
+        const int excl = block_excl_scan(keep, wtot, tot);
+        succ_removed += __syncthreads_count(in_ && ra);
+        if (keep) live[out + excl] = i;
+        out += tot;
+    }
+    return out;
+}
+
 // one access slot per launch: the arrivals of the slot have been activated by the host (prach_noma_activation_stream) before it
-__global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, const int *stream_, SlotCtl *ctl_, const NParams K) {
+struct LiveState { int nlive, succ_removed, prevAC, pad; }; // (device memory, zeroed before the first slot, kept from launch to launch)
+
+__global__ __launch_bounds__(WG_THREADS) void noma_glibc_slot_kernel(NUe *ue_, const int *stream_, SlotCtl *ctl_, int *live_, LiveState *ls_, const NParams K) {
     __shared__ int cnt[6 * 64], who[6 * 64], wtot[NW], sh[8], gs_idx[64];
     __shared__ double gs_g[64], gs_lg[64];
     NG SlotCtl *const ctl = (NG SlotCtl *)ctl_;
+    NG NUe *const ue = (NG NUe *)ue_;
+    NG int *const live = (NG int *)live_;
+    NG LiveState *const ls = (NG LiveState *)ls_;
+    const int tid = threadIdx.x, ac = ctl->activeCheck;
+    int nlive = ls->nlive, succ_removed = ls->succ_removed;
+    const int prevAC = ls->prevAC;
     unsigned long long pos = ctl->pos;
+    __syncthreads(); // (everybody has read the state thread 0 rewrites below)
+    for (int i = prevAC + tid; i < ac; i += WG_THREADS) live[nlive + (i - prevAC)] = i; // the slot's arrivals (activated by the host) join the list
+    nlive += ac - prevAC;
+    __syncthreads();
     int status = PRACH_OK, exit_time = -1, nsucc = 0;
-    noma_glibc_slot((NG NUe *)ue_, (const NG int *)stream_, K, cnt, who, wtot, sh, gs_idx, gs_g, gs_lg, ctl->time, ctl->activeCheck, nullptr, 0, 0, ctl->stream_len, false, pos, status, exit_time, nsucc);
-    if (threadIdx.x == 0) {
+    noma_glibc_slot(ue, (const NG int *)stream_, K, cnt, who, wtot, sh, gs_idx, gs_g, gs_lg, ctl->time, ac, live, nlive, succ_removed, ctl->stream_len, false, pos, status, exit_time, nsucc);
+    if (status == PRACH_OK && exit_time < 0) nlive = noma_live_compact(ue, live, nlive, wtot, succ_removed);
+    if (tid == 0) {
         ctl->pos = pos;
         ctl->nSuccess = nsucc;
         ctl->exit_time = exit_time;
         ctl->status = status;
+        ls->nlive = nlive; ls->succ_removed = succ_removed; ls->prevAC = ac;
     }
 }
 
@@ -368,23 +402,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_glibc_trial_kernel(const Tria
         steps = (unsigned long long)min(t + aT, K.stop);
         if (status != PRACH_OK) break;
         if (ex >= 0) { time_exit = ex; steps = (unsigned long long)ex + 1ull; break; }
-        // the UEs that succeeded or were dropped in this slot leave the list: stable compaction in place, 1024 entries at a time (an entry only ever
-        // moves down, and the barriers of the block-wide prefix separate a block's reads from the writes of the next)
-        {
-            int out = 0;
-            for (int c0 = 0; c0 < nlive; c0 += WG_THREADS) {
-                const bool in_ = c0 + tid < nlive;
-                const int i = in_ ? live[c0 + tid] : 0;
-                int keep = 0, ra = 0;
-                if (in_) { const NG NUe &u = ue[i]; ra = u.RA == 1 ? 1 : 0; keep = (ra || u.RaFailed != 0) ? 0 : 1; }
-                int tot;
-                const int excl = block_excl_scan(keep, wtot, tot);
-                succ_removed += __syncthreads_count(in_ && ra);
-                if (keep) live[out + excl] = i;
-                out += tot;
-            }
-            nlive = out;
-        }
+        nlive = noma_live_compact(ue, live, nlive, wtot, succ_removed);
         __syncthreads();
     }
     __syncthreads();
@@ -451,6 +469,8 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
     NUe *d_ue = nullptr;
     int *d_stream = nullptr;
     SlotCtl *d_ctl = nullptr, *h_ctl = nullptr;
+    int *d_live = nullptr;
+    LiveState *d_ls = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<NUe> hue((size_t)nUE);
     std::vector<int32_t> sched((size_t)(maxTime / aT + 2), nUE);
@@ -465,6 +485,9 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
     NHIP(hipMalloc(reinterpret_cast<void **>(&d_ue), sizeof(NUe) * (size_t)nUE));
     NHIP(hipMalloc(reinterpret_cast<void **>(&d_stream), 4 * (size_t)(len + 2)));
     NHIP(hipMalloc(reinterpret_cast<void **>(&d_ctl), sizeof(SlotCtl)));
+    NHIP(hipMalloc(reinterpret_cast<void **>(&d_live), 4 * (size_t)nUE + 64));
+    NHIP(hipMalloc(reinterpret_cast<void **>(&d_ls), sizeof(LiveState)));
+    NHIP(hipMemsetAsync(d_ls, 0, sizeof(LiveState), stream));
     NHIP(hipHostMalloc(reinterpret_cast<void **>(&h_ctl), sizeof(SlotCtl), hipHostMallocDefault));
     NHIP(hipEventCreate(&ev0));
     NHIP(hipEventCreate(&ev1));
@@ -488,7 +511,7 @@ int run_noma_glibc_trial(hipStream_t stream, const prach_cfg &c, const int32_t *
         h_ctl->pos = pos; h_ctl->stream_len = len; h_ctl->time = t; h_ctl->activeCheck = activeCheck; h_ctl->nSuccess = 0; h_ctl->exit_time = -1;
         h_ctl->status = PRACH_OK; h_ctl->pad = 0;
         NHIP(hipMemcpyAsync(d_ctl, h_ctl, sizeof(SlotCtl), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(noma_glibc_slot_kernel, dim3(1), dim3(WG_THREADS), 0, stream, d_ue, d_stream, d_ctl, K);
+        hipLaunchKernelGGL(noma_glibc_slot_kernel, dim3(1), dim3(WG_THREADS), 0, stream, d_ue, d_stream, d_ctl, d_live, d_ls, K);
         NHIP(hipGetLastError());
         NHIP(hipMemcpyAsync(h_ctl, d_ctl, sizeof(SlotCtl), hipMemcpyDeviceToHost, stream));
         NHIP(hipStreamSynchronize(stream));
@@ -511,6 +534,8 @@ done:
     if (d_ue) (void)hipFree(d_ue);
     if (d_stream) (void)hipFree(d_stream);
     if (d_ctl) (void)hipFree(d_ctl);
+    if (d_live) (void)hipFree(d_live);
+    if (d_ls) (void)hipFree(d_ls);
     if (h_ctl) (void)hipHostFree(h_ctl);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
