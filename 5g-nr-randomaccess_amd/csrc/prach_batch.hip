@@ -19,7 +19,10 @@
 //     in, one out, plus the pass word (the general kernel touched up to seven arrays per event; profiles/r03_config3.md).
 //   * The event body is prach_ue_body.h (shared with every other kernel); the resolver is prach_cluster.hip's for one workgroup.
 //   * No per-subframe capacity on the event queue or on the resolver's event list: both continue in global memory behind their LDS part.
-// Limits (the engine falls back to prach::cluster_kernel): Philox draws, nPreamble <= 64, maxRarWindow <= 64, < 65 000 subframes.
+//   * batch_kernel<16, true>: the same in the reference's own rand() stream (what `prach_sim -t 100` issues per sweep point) — the event body
+//     runs as a count pass + a block-wide prefix over the 64-UE groups + a select pass, see the kernel's head.
+//   * PRACH_FLAG_SECTOR_GRANTS (WithNOMA:626-637): six grant budgets in the grant phase.
+// Limits (the engine falls back to prach::cluster_kernel): nPreamble <= 64, maxRarWindow <= 64, < 65 000 subframes; the reference-stream form: 131 072 UEs.
 // Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351; decomposition: DESIGN.md section 3.
 #include "prach_device.h"
 #include "prach_device_fn.h"
