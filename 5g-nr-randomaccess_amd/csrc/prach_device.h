@@ -119,6 +119,8 @@ int batch_max_groups(bool glibc = false);
 hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, int waves, bool glibc, hipStream_t stream);
 constexpr int STREAM_CHUNK = 31 * 2048; // rand() outputs generated per wavefront (prach_stream.hip)
 hipError_t launch_glibc_stream(const unsigned *seeds, int *out, unsigned long long n, hipStream_t stream);
+struct StreamJob { const unsigned *seeds; int *out; unsigned long long n; }; // one trial's window: a 31-word seed window per chunk, n values out
+hipError_t launch_glibc_stream_jobs(const StreamJob *jobs, int njobs, unsigned long long max_n, hipStream_t stream); // (jobs: device memory)
 extern "C" void prach_internal_glibc_seeds(uint32_t seed, uint64_t first, uint64_t nchunks, uint64_t chunk, uint32_t *out);
 constexpr int CLUSTER_GLIBC_MAX_UE = 4096 * 64; // glibc mode on the cluster kernel: per-group draw counts live in LDS
 constexpr int CLUSTER_MAX_G = 64;

@@ -84,6 +84,7 @@ struct LaunchLayout {
     std::vector<TrialLayout> t;
     size_t staged_end = 0, zero_begin = 0, zero_end = 0, out0 = 0, end = 0;
     size_t act_flags = 0; // NOMA.c: noma_activation_kernel's list of UEs for the host (in the zeroed region)
+    size_t stream_jobs = 0; // glibc: StreamJob[m] (in the staged region)
 };
 
 size_t mbox_bytes(const prach_cfg &c, int G, int &evw, int &mbstride) {
@@ -113,6 +114,9 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         T.nchunks = (T.stream_len + STREAM_CHUNK - 1) / STREAM_CHUNK;
         T.seeds = T.stream_len ? take(4 * 31 * (T.nchunks + 1)) : 0;
     }
+    bool any_stream = false;
+    for (int k = 0; k < m; k++) any_stream = any_stream || stream_len[k] > 0;
+    if (any_stream) L.stream_jobs = take(sizeof(StreamJob) * (size_t)m);
     L.staged_end = o;
     L.zero_begin = o;
     L.out0 = take(sizeof(DevResult) * (size_t)m);
@@ -381,7 +385,10 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (rng_mode == PRACH_RNG_GLIBC)
             // the reference's rand() stream window [stream_offset, +stream_len): the host only jumps ahead (31-word window
             // per chunk, cached matrix powers); the values themselves are generated on the device inside the timed region
+        {
             prach_internal_glibc_seeds((uint32_t)c.seed, c.stream_offset, L.nchunks, STREAM_CHUNK, reinterpret_cast<uint32_t *>(H + L.seeds));
+            reinterpret_cast<StreamJob *>(H + LL.stream_jobs)[k] = StreamJob{reinterpret_cast<const unsigned *>(A + L.seeds), reinterpret_cast<int *>(A + L.stream), (unsigned long long)L.stream_len};
+        }
         if (noma) {
             d.n_pre0 = reinterpret_cast<const int *>(A + L.n_pre0); d.n_sector = reinterpret_cast<const int *>(A + L.n_sector);
             d.n_gain = reinterpret_cast<const double *>(A + L.n_gain); d.n_lgain = reinterpret_cast<const double *>(A + L.n_lgain);
@@ -438,10 +445,11 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     upload_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
 
     HIPCHK(hipEventRecord(e->ev0, e->stream));
-    if (rng_mode == PRACH_RNG_GLIBC)
-        for (int k = 0; k < m; k++)
-            HIPCHK(launch_glibc_stream(reinterpret_cast<const unsigned *>(A + LL.t[k].seeds), reinterpret_cast<int *>(A + LL.t[k].stream),
-                                       (unsigned long long)LL.t[k].stream_len, e->stream));
+    if (rng_mode == PRACH_RNG_GLIBC) { // every trial's stream window, ONE launch (a launch per trial: 0.45 ms each, prach_stream.hip)
+        unsigned long long max_n = 0;
+        for (int k = 0; k < m; k++) max_n = std::max(max_n, (unsigned long long)LL.t[k].stream_len);
+        HIPCHK(launch_glibc_stream_jobs(reinterpret_cast<const StreamJob *>(A + LL.stream_jobs), m, max_n, e->stream));
+    }
     if (noma && !host_act) { // activeUE for every UE of the launch, inside the timed region
         std::vector<ActTab> tabs(m);
         for (int k = 0; k < m; k++) tabs[k] = {A + LL.t[k].n_pre0, A + LL.t[k].n_sector, A + LL.t[k].n_gain, A + LL.t[k].n_lgain, A + LL.t[k].n_nd0};

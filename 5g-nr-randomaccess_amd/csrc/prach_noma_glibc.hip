@@ -568,6 +568,7 @@ int run_noma_glibc_batch(hipStream_t stream, const prach_cfg *const *cfgs, int n
     // staged prefix (one copy): argument blocks, control blocks (zeroed), stream seeds, arrival tables; then the per-trial arrays
     size_t o = up(sizeof(TrialArgs) * (size_t)n);
     const size_t octl = o; o = up(o + sizeof(TrialCtl) * (size_t)n);
+    const size_t ojobs = o; o = up(o + sizeof(StreamJob) * (size_t)n);
     for (int j = 0; j < n; j++) {
         const prach_cfg &c = *cfgs[j];
         off[j].nsched = (size_t)(maxTime / c.accessTime + 2);
@@ -599,12 +600,16 @@ int run_noma_glibc_batch(hipStream_t stream, const prach_cfg *const *cfgs, int n
         A.sched = reinterpret_cast<const int *>(dbuf + off[j].sched); A.live = reinterpret_cast<int *>(dbuf + off[j].live);
         A.ctl = reinterpret_cast<TrialCtl *>(dbuf + octl) + j; A.slen = lens[j]; A.cell_radius = c.cellRadius; A.pad = 0;
         A.K = NParams{c.nUE, c.nPreamble, c.backoff, c.nGrantUL, c.maxRarWindow, c.maxMsg2TxCount, c.accessTime, stop, (c.flags & PRACH_FLAG_NOMA_NONSECTOR) ? 1 : 0};
+        reinterpret_cast<StreamJob *>(hbuf + ojobs)[j] = StreamJob{reinterpret_cast<const unsigned *>(dbuf + off[j].seeds), reinterpret_cast<int *>(dbuf + off[j].stream), lens[j]};
         rcs[j] = PRACH_ERR_INTERNAL;
     }
     BHIP(hipMemcpyAsync(dbuf, hbuf, staged, hipMemcpyHostToDevice, stream));
     BHIP(hipEventRecord(ev0, stream));
-    for (int j = 0; j < n; j++)
-        BHIP(launch_glibc_stream(reinterpret_cast<const unsigned *>(dbuf + off[j].seeds), reinterpret_cast<int *>(dbuf + off[j].stream), lens[j], stream));
+    {
+        unsigned long long max_n = 0;
+        for (int j = 0; j < n; j++) max_n = std::max(max_n, lens[j]);
+        BHIP(launch_glibc_stream_jobs(reinterpret_cast<const StreamJob *>(dbuf + ojobs), n, max_n, stream)); // every window, one launch
+    }
     hipLaunchKernelGGL(noma_glibc_trial_kernel, dim3((unsigned)n), dim3(WG_THREADS), 0, stream, reinterpret_cast<const TrialArgs *>(dbuf));
     BHIP(hipGetLastError());
     BHIP(hipEventRecord(ev1, stream));

@@ -11,10 +11,9 @@
 
 namespace prach {
 
-__global__ __launch_bounds__(256) void glibc_stream_kernel(const unsigned *__restrict__ seeds, int *__restrict__ out,
-                                                           const unsigned long long n) {
+// one wavefront: the chunk c of a window of n values
+__device__ __forceinline__ void glibc_stream_chunk(const unsigned *__restrict__ seeds, int *__restrict__ out, const unsigned long long n, const unsigned long long c) {
     const int lane = threadIdx.x & 63;
-    const unsigned long long c = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const unsigned long long start = c * (unsigned long long)STREAM_CHUNK;
     if (start >= n) return;
     unsigned w = lane < 31 ? seeds[c * 31 + lane] : 0u;
@@ -33,10 +32,31 @@ __global__ __launch_bounds__(256) void glibc_stream_kernel(const unsigned *__res
     }
 }
 
+__global__ __launch_bounds__(256) void glibc_stream_kernel(const unsigned *__restrict__ seeds, int *__restrict__ out,
+                                                           const unsigned long long n) {
+    glibc_stream_chunk(seeds, out, n, (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
+
+// The windows of MANY trials in one launch (blockIdx.y = job): a chunk is a serial chain of 2048 steps (0.45 ms whatever the window's
+// length), so a launch per trial costs 0.45 ms each — 100 trials of a sweep point: 45 ms of a 245 ms call — while all chunks of all
+// windows side by side take about as long as one.
+__global__ __launch_bounds__(256) void glibc_stream_jobs_kernel(const StreamJob *__restrict__ jobs) {
+    const StreamJob J = jobs[blockIdx.y];
+    glibc_stream_chunk(J.seeds, J.out, J.n, (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
+
 hipError_t launch_glibc_stream(const unsigned *seeds, int *out, unsigned long long n, hipStream_t stream) {
     const unsigned long long nchunks = (n + STREAM_CHUNK - 1) / STREAM_CHUNK;
     if (nchunks == 0) return hipSuccess;
     hipLaunchKernelGGL(glibc_stream_kernel, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, stream, seeds, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_glibc_stream_jobs(const StreamJob *jobs, int njobs, unsigned long long max_n, hipStream_t stream) {
+    const unsigned long long nchunks = (max_n + STREAM_CHUNK - 1) / STREAM_CHUNK;
+    if (nchunks == 0 || njobs <= 0) return hipSuccess;
+    if (njobs > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(glibc_stream_jobs_kernel, dim3((unsigned)((nchunks + 3) / 4), (unsigned)njobs), dim3(256), 0, stream, jobs);
     return hipGetLastError();
 }
 
