@@ -385,10 +385,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (rng_mode == PRACH_RNG_GLIBC)
             // the reference's rand() stream window [stream_offset, +stream_len): the host only jumps ahead (31-word window
             // per chunk, cached matrix powers); the values themselves are generated on the device inside the timed region
-        {
-            prach_internal_glibc_seeds((uint32_t)c.seed, c.stream_offset, L.nchunks, STREAM_CHUNK, reinterpret_cast<uint32_t *>(H + L.seeds));
             reinterpret_cast<StreamJob *>(H + LL.stream_jobs)[k] = StreamJob{reinterpret_cast<const unsigned *>(A + L.seeds), reinterpret_cast<int *>(A + L.stream), (unsigned long long)L.stream_len};
-        }
         if (noma) {
             d.n_pre0 = reinterpret_cast<const int *>(A + L.n_pre0); d.n_sector = reinterpret_cast<const int *>(A + L.n_sector);
             d.n_gain = reinterpret_cast<const double *>(A + L.n_gain); d.n_lgain = reinterpret_cast<const double *>(A + L.n_lgain);
@@ -396,6 +393,20 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             d.cell_radius = c.cellRadius;
             d.n_devact = host_act ? 0 : (e->opt_noma_ambiguity_test ? 2 : 1);
         }
+    }
+    if (rng_mode == PRACH_RNG_GLIBC) { // one 31-word window per chunk of every trial's stream window: the trials dealt to the host cores (100 trials x 200 jump-aheads: 25 ms on one)
+        const int nth = std::min(host_threads(e), std::max(1, m));
+        auto work = [&](int tix) {
+            for (int k = tix; k < m; k += nth) {
+                const prach_cfg &c = cfgs[idx[k]];
+                const TrialLayout &L = LL.t[k];
+                prach_internal_glibc_seeds((uint32_t)c.seed, c.stream_offset, L.nchunks, STREAM_CHUNK, reinterpret_cast<uint32_t *>(H + L.seeds));
+            }
+        };
+        std::vector<std::thread> th;
+        for (int tix = 1; tix < nth; tix++) th.emplace_back(work, tix);
+        work(0);
+        for (auto &x : th) x.join();
     }
     if (noma && host_act) {
         // activeUE's per-UE attributes (NOMA.c:131-192: double-precision libm work, once per UE): built on the host with the
