@@ -33,6 +33,12 @@ struct prach_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     char *arena = nullptr;
     size_t arena_cap = 0;
+    // the arena as ONE reserved virtual range that physical memory is mapped into piece by piece (hipMemAddressReserve / hipMemCreate / hipMemMap): growing it
+    // maps the increment only — no hipFree + hipMalloc of the whole arena (measured 0.8-1.4 s for 10-16 GB when a sweep's calls grow point by point) — and
+    // its address never changes.  vmm: 0 untried, 1 in use, -1 unavailable (plain hipMalloc arena).
+    int vmm = 0;
+    size_t vmm_reserved = 0, vmm_gran = 0;
+    std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> vmm_parts;
     char *pinned = nullptr; // host staging mirror of the head of the arena (parameter blocks, arrival tables, stream seeds, results)
     size_t pinned_cap = 0;
     prach_timing last{};
@@ -55,6 +61,7 @@ struct prach_engine {
     int64_t opt_fast = 1;          // 0: LDS-resident clusters run on the general kernel (prach_cluster.hip) instead of prach_lcluster.hip
     int64_t opt_batch = 1;         // 0: one-workgroup-per-trial Philox launches run on the general kernel instead of prach_batch.hip
     int64_t opt_batch_waves = 0;   // wavefronts per batch-kernel workgroup: 8 (512 threads, two trials per CU), 16 (one), 0 = chosen per launch
+    int64_t opt_plain_arena = 0;   // 1: the arena is one hipMalloc allocation, re-allocated when it grows (diagnostic)
     int64_t opt_noma_host_activation = 0; // 1: NOMA.c's activeUE table is built on the host (the reference's libm) instead of by noma_activation_kernel
     int64_t opt_noma_ambiguity_test = 0;  // test hook: the resolver reports every gain sort as ambiguous (exercises the rerun with the host-built table)
     bool force_host_act = false;   // (set for the rerun of trials whose device-built table left a gain comparison inside the error band)
@@ -168,8 +175,56 @@ uint64_t stream_budget(const prach_cfg &c, int attempt, int64_t factor, double s
     return b << (2 * attempt);
 }
 
+// grows the reserved-range arena to at least `need` mapped bytes; false: the mechanism is not available here (nothing has been changed)
+static bool grow_vmm_arena(prach_engine *e, size_t need) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = e->device;
+    if (e->vmm == 0) {
+        size_t gran = 0, free_b = 0, total_b = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); e->vmm = -1; return false; }
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); e->vmm = -1; return false; }
+        const size_t reserve = align_up(total_b, gran); // (address space, not memory)
+        void *p = nullptr;
+        if (hipMemAddressReserve(&p, reserve, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); e->vmm = -1; return false; }
+        e->arena = static_cast<char *>(p); e->arena_cap = 0; e->vmm_reserved = reserve; e->vmm_gran = gran; e->vmm = 1;
+    }
+    if (need > e->vmm_reserved) return false;
+    // at least a quarter more than what is mapped, at least 256 MB: a sweep's growing calls map a handful of pieces in all
+    size_t delta = align_up(std::max(need - e->arena_cap, std::max(e->arena_cap >> 2, (size_t)256 << 20)), e->vmm_gran);
+    delta = std::min(delta, e->vmm_reserved - e->arena_cap);
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, delta, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemMap(e->arena + e->arena_cap, delta, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(e->arena + e->arena_cap, delta, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap(e->arena + e->arena_cap, delta); (void)hipMemRelease(h); return false; }
+    e->vmm_parts.push_back({h, delta});
+    e->arena_cap += delta;
+    return true;
+}
+static void free_arena(prach_engine *e) {
+    if (e->vmm == 1) {
+        size_t at = 0;
+        for (auto &pt : e->vmm_parts) { (void)hipMemUnmap(e->arena + at, pt.second); (void)hipMemRelease(pt.first); at += pt.second; }
+        e->vmm_parts.clear();
+        if (e->arena) (void)hipMemAddressFree(e->arena, e->vmm_reserved);
+    } else if (e->arena) (void)hipFree(e->arena);
+    e->arena = nullptr; e->arena_cap = 0;
+}
+
 int ensure_arena(prach_engine *e, size_t need) {
     if (need <= e->arena_cap) return PRACH_OK;
+    if (e->vmm >= 0 && !e->opt_plain_arena) {
+        if (grow_vmm_arena(e, need) && need <= e->arena_cap) return PRACH_OK;
+        if (e->vmm == 1) { // the range is in use but could not grow (out of memory / of range): back to one plain allocation
+            std::fprintf(stderr, "[prach] the reserved-range arena could not grow to %zu bytes: falling back to hipMalloc\n", need);
+            free_arena(e);
+        }
+        e->vmm = -1;
+    }
     const size_t had = e->arena_cap;
     if (e->arena) HIPCHK(hipFree(e->arena));
     e->arena = nullptr;
@@ -881,7 +936,7 @@ int prach_engine_create(int device, prach_engine **out) {
 void prach_engine_destroy(prach_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->arena) (void)hipFree(e->arena);
+    free_arena(e);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -902,6 +957,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "batch") == 0) { e->opt_batch = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "plain_arena") == 0) { if (e->arena_cap) return PRACH_ERR_ARG; e->opt_plain_arena = value != 0; return PRACH_OK; } // (before the first call only)
     if (std::strcmp(key, "noma_ambiguity_test") == 0) { e->opt_noma_ambiguity_test = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "noma_host_activation") == 0) { e->opt_noma_host_activation = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "batch_waves") == 0) { if (value != 0 && value != 8 && value != 16) return PRACH_ERR_ARG; e->opt_batch_waves = value; return PRACH_OK; }
