@@ -311,16 +311,17 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         for (int j = 0; j < count; j++) {
                             const double gj = L.sg[sct * 64 + j];
                             rank += (gj < ug || (gj == ug && j < lane)) ? 1 : 0;
-                            // device-built table: two gains closer than the error band of the device's libm (~90 ulp) could be ordered the other way by the reference's
-                            if (devact && j != lane && (fabs(__dsub_rn(gj, ug)) <= 1e-14 * fmax(gj, ug) || P.n_devact == 2)) ambiguous = true; // (2: test hook, every sort counts as ambiguous)
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (lane < count) { L.sidx[sct * 64 + rank] = uidx; L.slg[sct * 64 + rank] = ulg; }
+                    if (lane < count) { L.sidx[sct * 64 + rank] = uidx; L.slg[sct * 64 + rank] = ulg; L.sg[sct * 64 + rank] = ug; } // (every lane has read the unsorted gains: barrier above)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     int cidx = -1;
                     double clg = 0;
                     if (lane < count) { cidx = L.sidx[sct * 64 + lane]; clg = L.slg[sct * 64 + lane]; }
+                    // device-built table: two gains closer than the error band of the device's libm (~90 ulp) could be ordered the other way by the reference's —
+                    // in sorted order it is enough to look at neighbours (n_devact == 2: test hook, every sort counts as ambiguous)
+                    if (devact && lane + 1 < count) { const double ga = L.sg[sct * 64 + lane], gb = L.sg[sct * 64 + lane + 1]; if (__dsub_rn(gb, ga) <= 1e-14 * gb || P.n_devact == 2) ambiguous = true; }
                     NSTAMP(9); // resolve: ranked and sorted
                     unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
                     int grants = 0, npd = 0;

@@ -129,15 +129,16 @@ __device__ __forceinline__ void noma_glibc_slot(NG NUe *const ue, const NG int *
                 for (int j = 0; j < count; j++) {
                     const double gj = gs_g[j];
                     rank += (gj < ug || (gj == ug && j < lane)) ? 1 : 0;
-                    if (devact && j != lane && fabs(__dsub_rn(gj, ug)) <= 1e-14 * fmax(gj, ug)) ambiguous = true; // (the libm's gains could order the two the other way)
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < count) { gs_idx[rank] = uidx; gs_lg[rank] = ulg; }
+            if (lane < count) { gs_idx[rank] = uidx; gs_lg[rank] = ulg; gs_g[rank] = ug; } // (every lane has read the unsorted gains: barrier above)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int cidx = -1;
             double clg = 0;
             if (lane < count) { cidx = gs_idx[lane]; clg = gs_lg[lane]; }
+            // (the libm's gains could order two neighbours of the sorted order the other way: within the error band of the device's)
+            if (devact && lane + 1 < count) { const double ga = gs_g[lane], gb = gs_g[lane + 1]; if (__dsub_rn(gb, ga) <= 1e-14 * gb) ambiguous = true; }
             unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
             int grants = 0;
             bool grantme = false;
