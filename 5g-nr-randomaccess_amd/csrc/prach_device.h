@@ -85,6 +85,7 @@ struct TrialDev {
     unsigned *pw;                // [whole 64-UE groups] pass words
     int *qov;                    // [nUE] event queue of a subframe beyond its LDS part
     int2 *evov;                  // [2 nUE] the resolver's event list of a subframe beyond its LDS part
+    unsigned long long *diag;    // diagnostic build (PRACH_STAMPS) only: [CLUSTER_MAX_G][32] per-workgroup phase stamps of a cluster trial; else null
 };
 
 constexpr int WG_THREADS = 1024;

@@ -77,6 +77,7 @@ struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, cand;
     size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0, sector;
     size_t rec32, pw, qov, evov; // batch kernel
+    size_t diag;                 // diagnostic build: per-workgroup stamps (zeroed region)
     size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
     int evw, mbstride;
@@ -131,6 +132,11 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         L.t[k].out = L.out0 + sizeof(DevResult) * (size_t)k;
         const size_t mb = mbox_bytes(cfgs[idx[k]], G, L.t[k].evw, L.t[k].mbstride);
         L.t[k].mbox = mb ? take(mb) : 0;
+#ifdef PRACH_STAMPS
+        L.t[k].diag = G > 1 ? take(8 * 32 * (size_t)CLUSTER_MAX_G) : 0;
+#else
+        L.t[k].diag = 0;
+#endif
     }
     if (cfgs[idx[0]].variant == PRACH_VARIANT_NOMA_C) L.act_flags = take(4 * (2 + 2 * (size_t)NOMA_ACT_FLAG_CAP));
     L.zero_end = o;
@@ -421,6 +427,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.mbox = L.mbox ? reinterpret_cast<int *>(A + L.mbox) : nullptr;
         d.cand = L.cand ? reinterpret_cast<int2 *>(A + L.cand) : nullptr;
         d.flags = c.flags;
+        d.diag = L.diag ? reinterpret_cast<unsigned long long *>(A + L.diag) : nullptr;
         d.sector = L.sector ? reinterpret_cast<int *>(A + L.sector) : nullptr;
         int32_t *sched = reinterpret_cast<int32_t *>(H + L.sched);
         // the arrival table depends on (nUE, traffic law, accessTime) only: a sweep x seeds batch has a handful of distinct ones
@@ -626,9 +633,22 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             static const char *const nmn[24] = {"head", "publish+gather", "gather-barrier", "resolve(w0)", "resolve-barrier", "passB+A(w0)", "pass-barrier", "-", "r:to-gains", "r:rank+sort", "r:pairing", "-", "-", "-", "-", "-",
                                                 "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_noma.hip, per SUBFRAME (x accessTime = per slot)
             const char *const *const names = noma ? nmn : e->last.rec_mode == CLUSTER_REC_BATCH ? nmb : nm;
-            std::fprintf(stderr, "[prach fine stamps/step]");
+            std::fprintf(stderr, "[prach fine stamps/step] nUE=%d steps=%llu", c.nUE, (unsigned long long)dr.steps);
             for (int q = 0; q < 20; q++) if (names[q][0] != '-') std::fprintf(stderr, " %s=%.0f", names[q], dr.fstamps[q] / (double)dr.steps);
             std::fprintf(stderr, "\n");
+        }
+        if (L.diag && e->last.rec_mode == CLUSTER_REC_LFAST && std::getenv("PRACH_PRINT_STAMPS") && std::atoi(std::getenv("PRACH_PRINT_STAMPS")) >= 2) {
+            // every workgroup of the cluster on its own clock (thread PRACH_STAMP_TID): cycles per subframe and phase, then its event UEs per subframe
+            std::vector<unsigned long long> dg(32 * (size_t)G);
+            HIPCHK(hipMemcpy(dg.data(), A + L.diag, 8 * dg.size(), hipMemcpyDeviceToHost));
+            static const char *const nm[20] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "window-rest", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "-",
+                                               "w:phaseA", "w:loads", "w:refill", "t:buckets"};
+            for (int b_ = 0; b_ < G; b_++) {
+                std::fprintf(stderr, "[prach wg stamps/step] nUE=%d steps=%llu b=%d", c.nUE, (unsigned long long)dr.steps, b_);
+                for (int q = 0; q < 20; q++) if (nm[q][0] != '-') std::fprintf(stderr, " %s=%.0f", nm[q], dg[32 * (size_t)b_ + q] / (double)dr.steps);
+                std::fprintf(stderr, " queued=%.2f late-buckets=%.3f late-header=%.3f refills=%.2f\n", dg[32 * (size_t)b_ + 24] / (double)dr.steps, dg[32 * (size_t)b_ + 25] / (double)dr.steps,
+                             dg[32 * (size_t)b_ + 26] / (double)dr.steps, dg[32 * (size_t)b_ + 27] / (double)dr.steps);
+            }
         }
         if (dr.status != PRACH_OK && e->last.rec_mode == CLUSTER_REC_LFAST && std::getenv("PRACH_VERBOSE"))
             std::fprintf(stderr, "[prach] lcluster_kernel: trial nUE=%d left at subframe %d with status %d, capacity code %d\n", c.nUE, dr.time_exit, dr.status, dr.hard_error);

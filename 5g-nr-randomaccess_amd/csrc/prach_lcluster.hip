@@ -1056,6 +1056,9 @@ __global__ __launch_bounds__(WG_THREADS) void lcluster_kernel(const TrialDev *__
         gadd(&o->continueFailed, scal[S_CONTF]);
         if (status != PRACH_OK) gmin(&o->status, status);
         if (status == PRACH_ERR_INTERNAL) o->hard_error = 1; // (a capacity was exceeded: that, not a peer's time-out, is what the engine must act on)
+#ifdef PRACH_STAMPS
+        if (PD->diag) for (int k = 0; k < 28; k++) ((PRACH_G unsigned long long *)PD->diag)[b * 32 + k] = fstamps[k]; // (every workgroup's own clock: dstat follows the 24 stamps)
+#endif
         if (b == 0) {
 #ifdef PRACH_STAMPS
             for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];

@@ -319,9 +319,9 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     int cidx = -1;
                     double clg = 0;
                     if (lane < count) { cidx = L.sidx[sct * 64 + lane]; clg = L.slg[sct * 64 + lane]; }
-                    // device-built table: two gains closer than the error band of the device's libm (~90 ulp) could be ordered the other way by the reference's —
+                    // device-built table: two gains closer than the error band of the device's libm (ACT_GAIN_ORDER_BAND, prach_noma_act.h: twice the asserted per-gain error, with margin) could be ordered the other way by the reference's —
                     // in sorted order it is enough to look at neighbours (n_devact == 2: test hook, every sort counts as ambiguous)
-                    if (devact && lane + 1 < count) { const double ga = L.sg[sct * 64 + lane], gb = L.sg[sct * 64 + lane + 1]; if (__dsub_rn(gb, ga) <= 1e-14 * gb || P.n_devact == 2) ambiguous = true; }
+                    if (devact && lane + 1 < count) { const double ga = L.sg[sct * 64 + lane], gb = L.sg[sct * 64 + lane + 1]; if (__dsub_rn(gb, ga) <= ACT_GAIN_ORDER_BAND * gb || P.n_devact == 2) ambiguous = true; }
                     NSTAMP(9); // resolve: ranked and sorted
                     unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
                     int grants = 0, npd = 0;

@@ -18,6 +18,15 @@
 namespace prach {
 
 constexpr long long ACT_BAND = 64;
+// Gains downstream.  tests/test_noma.py asserts that the gain of every UNFLAGGED UE is within ACT_GAIN_ULP_ASSERTED ulps of the host libm's
+// (measured worst case: 6).  Two gains may each be off by that much in opposite directions, i.e. their difference by 2 x 32 ulps = at most
+// 64 x 2^-52 = 1.42e-14 relative to the larger one (an ulp is 2^-52 of a mantissa of 1.0: the worst case).  The resolver treats the ORDER of
+// two sorted neighbours as undecided (NOMA_AMBIGUOUS: the trial is rerun with the host-built table) when gb - ga <= ACT_GAIN_ORDER_BAND x gb;
+// the band must cover that and does with a margin of 2.8: 4e-14 > 2 x ACT_GAIN_ULP_ASSERTED x 2^-52.  ln g is then within 32 ulp(g) / g + one
+// libm ulp, i.e. |error of 10 ln g1 - 10 ln g2| < 1e-12 — the pairing test's own band around 15.0 (1e-9) is a thousand times that.
+constexpr int ACT_GAIN_ULP_ASSERTED = 32;
+constexpr double ACT_GAIN_ORDER_BAND = 4e-14;
+static_assert(ACT_GAIN_ORDER_BAND > 2.0 * ACT_GAIN_ULP_ASSERTED * 2.220446049250313e-16, "the order band covers two gains off by the asserted bound in opposite directions");
 
 __device__ __forceinline__ bool near_float_boundary(const double p) { // could (float)p differ from (float)p' for |p' - p| <= ACT_BAND ulps?
     const unsigned long long bits = (unsigned long long)__double_as_longlong(p);

@@ -138,7 +138,7 @@ __device__ __forceinline__ void noma_glibc_slot(NG NUe *const ue, const NG int *
             double clg = 0;
             if (lane < count) { cidx = gs_idx[lane]; clg = gs_lg[lane]; }
             // (the libm's gains could order two neighbours of the sorted order the other way: within the error band of the device's)
-            if (devact && lane + 1 < count) { const double ga = gs_g[lane], gb = gs_g[lane + 1]; if (__dsub_rn(gb, ga) <= 1e-14 * gb) ambiguous = true; }
+            if (devact && lane + 1 < count) { const double ga = gs_g[lane], gb = gs_g[lane + 1]; if (__dsub_rn(gb, ga) <= ACT_GAIN_ORDER_BAND * gb) ambiguous = true; }
             unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
             int grants = 0;
             bool grantme = false;

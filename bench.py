@@ -21,8 +21,11 @@ torch.distributed.run, one rank per GPU (RCCL).  One JSON line on rank 0.
           HIP events on the engine's own stream (prach_last_timing) — an ALGORITHMIC rate: a single trial is
           10 000 dependent subframes over LDS/L2-resident state, bounded by per-subframe latency, not by HBM
           (measured HBM traffic: `traffic_from_profile`, a separate rocprofv3 --pmc pass, profiles/).
-  cpu_baseline  the real reference binary (oracle/_ref, built from /root/reference in the build container) on one
-          host core for a bounded sample of its own hard-coded sweep (it cannot be started at nUE=100 000);
+  cpu_baseline  the real reference program AT THE METRIC'S OWN SIZE, timed in this run: oracle/_ref/RandomAccessSimulatorBeta_100k
+          (RandomAccessSimulatorBeta.c compiled with its hard-coded sweep started at nUE = 100 000, built from /root/reference in the
+          build container) is started as a child process on one host core right behind the timed region, runs while the extras and the
+          other CPU legs do, and is joined at the end (about 67 s on a GPU box);
+          `cpu_reference_small_points`: the unmodified binary on the first points (10k..) of its own sweep for --cpu-budget seconds;
           `cpu_port`: the oracle's O(N)-per-subframe restatement on the full N=1 workload, one core;
           `cpu_port_all_cores`: the same restatement on 100 000-UE trials fanned over all host cores.
 """
@@ -99,33 +102,60 @@ def cpu_reference_baseline(budget_s: float):
 REF100K_RECORD = os.path.join(ROOT, "profiles", "r03_cpu_reference_100k.json")
 
 
-def cpu_reference_at_100k(full: bool):
+def start_reference_100k():
     """The reference's CPU path AT THE METRIC'S OWN SIZE: oracle/_ref/RandomAccessSimulatorBeta_100k is RandomAccessSimulatorBeta.c
     compiled with its hard-coded sweep started at nUE = 100 000 (oracle/Makefile SED_BETA_100K: one token of line 71), i.e. the
-    reference's own 100 000-UE point from srand(0) — about five minutes on one core, so it only runs with --cpu-full; a default run
-    carries the record of the last such run on a GPU box (profiles/r03_cpu_reference_100k.json), or says that there is none."""
+    reference's own 100 000-UE point from srand(0) (Beta.c:71,111-183,205-206).  Started as a CHILD process (one core, like the
+    reference) and joined later: about 67 s on a GPU box's host, during which this process runs its extras and other CPU legs."""
     exe = os.path.join(ROOT, "oracle", "_ref", "RandomAccessSimulatorBeta_100k")
-    if full and os.path.exists(exe):
-        with tempfile.TemporaryDirectory() as d:
-            os.makedirs(os.path.join(d, "BasicBetaSimulationResults"))
-            t0 = time.perf_counter()
-            p = subprocess.run([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-            wall = time.perf_counter() - t0
-            lines = open(os.path.join(d, "BasicBetaSimulationResults", "0_54_100000_Results.txt")).read().split("\n")
-            tsim = [int(l.split(":")[1].replace("ms", "")) for l in p.stdout.split("\n") if l.startswith("Total simulation time:")][0]
-            steps = min(10000, tsim + 1)
-            rec = {"value": 100000.0 * steps / float(lines[5]), "unit": "UE-subframe updates/s", "cores": 1, "kind": "reference",
-                   "sample": f"oracle/_ref/RandomAccessSimulatorBeta_100k: the reference's nUE = 100 000 point alone from srand(0), {steps} subframes, "
-                             f"{float(lines[5]):.1f} s of clock() ({wall:.1f} s wall), success ratio {lines[1]} %",
-                   "measured_in_this_run": True, "host": os.uname().nodename, "host_cores": host_cores()}
-            return rec
+    if not os.path.exists(exe):
+        return None
+    d = tempfile.mkdtemp(prefix="prach_ref100k_")
+    os.makedirs(os.path.join(d, "BasicBetaSimulationResults"))
+    p = subprocess.Popen([exe], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    return {"p": p, "dir": d, "t0": time.perf_counter()}
+
+
+def join_reference_100k(h, timeout_s: float):
+    """Wait for the child of start_reference_100k and turn its Results.txt (cumulative clock() seconds, Beta.c:205-206,481) and its
+    'Total simulation time' line into a cpu_baseline record; None when it did not finish (it is killed then)."""
+    import shutil
+    if h is None:
+        return None
+    p = h["p"]
+    try:
+        so, _ = p.communicate(timeout=max(1.0, timeout_s))
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        shutil.rmtree(h["dir"], ignore_errors=True)
+        return None
+    wall = time.perf_counter() - h["t0"]
+    try:
+        lines = open(os.path.join(h["dir"], "BasicBetaSimulationResults", "0_54_100000_Results.txt")).read().split("\n")
+        tsim = [int(l.split(":")[1].replace("ms", "")) for l in so.split("\n") if l.startswith("Total simulation time:")][0]
+        steps = min(10000, tsim + 1)
+        secs = float(lines[5])
+        rec = {"value": 100000.0 * steps / secs, "unit": "UE-subframe updates/s", "cores": 1, "kind": "reference",
+               "sample": f"oracle/_ref/RandomAccessSimulatorBeta_100k: the reference's own nUE = 100 000 point from srand(0) (54 preambles, nGrantUL 54, "
+                         f"retx 10), all {steps} subframes, {secs:.1f} s of clock() on one core ({wall:.1f} s wall, as a child process beside this "
+                         f"run's extras and CPU legs), success ratio {lines[1]} %",
+               "measured_in_this_run": True, "host": os.uname().nodename, "host_cores": host_cores()}
+    except Exception as e:  # the child wrote nothing usable
+        rec = None
+        print(f"bench.py: reference 100k child: {e!r}", file=sys.stderr)
+    shutil.rmtree(h["dir"], ignore_errors=True)
+    return rec
+
+
+def reference_100k_record():
+    """(only when the child could not run: the record of an earlier run on a GPU box, marked as not measured here)"""
     if os.path.exists(REF100K_RECORD):
         rec = json.load(open(REF100K_RECORD))
         rec["measured_in_this_run"] = False
         rec["source"] = "profiles/r03_cpu_reference_100k.json: `python bench.py --cpu-full` on a GPU box in round 3"
         return rec
-    return {"value": 3.8e6, "unit": "UE-subframe updates/s", "cores": 1, "measured_in_this_run": False,
-            "source": "SURVEY.md §6: the reference's own 100k point, 263 s in the build container, same binary (no --cpu-full record yet)"}
+    return None
 
 
 def cpu_port_all_cores(ob, nue: int, ntrials: int):
@@ -164,6 +194,23 @@ def traffic_from_profile():
         return None
 
 
+def checked_traffic(prof, rec_mode: int, k_ms: float):
+    """roofline.traffic = counter-measured HBM bytes per launch (FETCH_SIZE x the calibrated 2 + WRITE_SIZE, separate rocprofv3 --pmc
+    passes of this same command: profiles/traffic.json) — carried only while the profiled kernel IS this run's kernel and its mean
+    duration under the profiler is within 5 % of this run's; otherwise null and the reason."""
+    if prof is None:
+        return None, "no profiles/traffic.json"
+    name = prof.get("kernel", "")
+    mine = "lcluster_kernel" if rec_mode == 3 else "batch_kernel" if rec_mode == 4 else "cluster_kernel"
+    if ("prach::" + mine) not in name:
+        return None, f"profiles/traffic.json was taken on `{name}`, this run's kernel is prach::{mine}: not carried"
+    prof_ms = float(prof.get("avg_kernel_ns", 0.0)) * 1e-6
+    if k_ms <= 0 or abs(prof_ms - k_ms) / k_ms > 0.05:
+        return None, f"profiles/traffic.json: kernel mean {prof_ms:.2f} ms under the profiler vs {k_ms:.2f} ms in this run (> 5 %): stale, not carried"
+    return float(prof["hbm_bytes_per_launch"]), (f"profiles/traffic.json ({prof.get('tag', '?')}): {prof.get('method', '')}; kernel `{name}`, "
+                                                  f"{prof_ms:.2f} ms under the profiler vs {k_ms:.2f} ms here")
+
+
 def relaunch_under_torchrun(args) -> int:
     """`python bench.py --gpus N` (N > 1) without a torch.distributed rendezvous in the environment: run the same command line as
     N ranks in a child process.  Returns the child's exit code; a node with fewer than N GPUs is an error, not a smaller run."""
@@ -198,7 +245,8 @@ def main():
     ap.add_argument("--workload", choices=("auto", "single", "grid"), default="auto", help="auto: single trial at N=1, the sharded grid at N>1")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of reference-CPU timing (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-full", action="store_true", help="also run the reference binary's own nUE = 100 000 point to the end (about five minutes on one core)")
+    ap.add_argument("--cpu-full", action="store_true", help="(kept for old command lines: the reference's own nUE = 100 000 point now runs by default, as a child process)")
+    ap.add_argument("--cpu-ref-timeout", type=float, default=420.0, help="seconds after which the reference's 100 000-UE child process is given up (67 s on a GPU box, 265 s in the build container)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL over xGMI; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -373,6 +421,8 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
     barrier()
     dt = time.perf_counter() - t0
     assert fallbacks == 0, "a timed trial was rerun on the fallback kernel"
+    # the reference's own 100 000-UE point: a child process on one host core, started behind the timed region, joined at the very end
+    ref100k = start_reference_100k() if (world == 1 and rank == 0 and not args.no_cpu) else None
 
     tot_updates, max_dt = updates, dt
     if dist is not None:
@@ -389,6 +439,7 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
     k_ms = kernel_ms / args.steps
     achieved = ALGO_BYTES_PER_UPDATE * per_launch_updates / (k_ms * 1e-3) / 1e9
     prof = traffic_from_profile()
+    traffic, traffic_note = checked_traffic(prof, tm.rec_mode, k_ms)
     out = {
         "metric": "UE-subframe updates/sec at nUE=100k Beta; bit-exact success-ratio vs ref",
         "value": value, "unit": "UE-subframe updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -399,12 +450,14 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
                    "rng": "philox4x32-10 (production mode)", "trials_per_step_per_gpu": 1,
                    "updates_per_step_per_gpu": per_launch_updates, "parallelism": f"one trial per GPU x {world} GPU(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "traffic_from_profile": prof,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2.000 + WRITE_SIZE)", "traffic_provenance": traffic_note,
+                     "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UPDATE * per_launch_updates,
                      "kernel": f"{KERNEL_NAMES.get(tm.rec_mode, '?')}, {tm.cluster_size} workgroups per trial", "kernel_ms": k_ms,
                      "us_per_subframe": 1e3 * k_ms / (per_launch_updates / args.nue),
                      "note": "achieved = ALGORITHMIC bytes (32 B per UE-subframe update, SURVEY 8d) / kernel time.  The single-trial workload is 1e4 dependent "
                              "subframes over LDS-resident state: bounded by the per-subframe latency chain (one cross-CU exchange + dependent phases), not by "
-                             "HBM; counter-measured HBM traffic of this kernel is in traffic_from_profile (separate rocprofv3 --pmc passes, profiles/)"},
+                             "HBM; `traffic` is this kernel's counter-measured HBM traffic per launch (separate rocprofv3 --pmc passes, profiles/): far BELOW the algorithmic bytes "
+                             "because the UE state lives in LDS for the whole trial"},
         "success_ratio_mean": agg_succ / (args.steps * world * args.nue),
         "host_cores": {"os_cpu_count": os.cpu_count(), "usable_by_this_process": host_cores()},
     }
@@ -532,14 +585,19 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
                          "nSuccessUE": r0.nSuccessUE}
         out["cpu_port"] = {"value": args.nue * ores.steps / osec, "unit": "UE-subframe updates/s", "cores": 1, "kind": "port",
                            "sample": f"oracle O(N)/subframe restatement, the full workload (nUE={args.nue}, {ores.steps} subframes), {osec:.1f} s"}
-        out["cpu_port_all_cores"] = cpu_port_all_cores(ob, args.nue, 2 * host_cores())
-        ref = cpu_reference_baseline(args.cpu_budget)
-        at100k = cpu_reference_at_100k(args.cpu_full)
-        if ref is not None:
-            ref["at_nUE_100000"] = at100k
-        out["cpu_baseline"] = ref if ref is not None else out["cpu_port"]
-        if args.cpu_full and at100k.get("measured_in_this_run"):
-            out["cpu_baseline_at_metric_size"] = at100k
+        ref_small = cpu_reference_baseline(args.cpu_budget)  # (one more single-threaded child beside the 100k one: the host has the cores)
+        at100k = join_reference_100k(ref100k, args.cpu_ref_timeout - (time.perf_counter() - ref100k["t0"])) if ref100k is not None else None
+        out["cpu_port_all_cores"] = cpu_port_all_cores(ob, args.nue, 2 * host_cores())  # (behind the join: it takes every core)
+        if ref_small is not None:
+            ref_small.pop("at_nUE_100000", None)
+            out["cpu_reference_small_points"] = ref_small
+        if at100k is not None:
+            out["cpu_baseline"] = at100k
+        else:  # no binary on this box, or it did not finish: say so, carry what there is
+            fb = ref_small if ref_small is not None else dict(out["cpu_port"])
+            fb["at_nUE_100000"] = reference_100k_record()
+            fb["note"] = "oracle/_ref/RandomAccessSimulatorBeta_100k was not available or did not finish within --cpu-ref-timeout: this is NOT the nUE = 100 000 figure"
+            out["cpu_baseline"] = fb
     return out
 
 

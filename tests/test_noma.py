@@ -119,7 +119,7 @@ def test_gpu_noma_full_size_and_statistics(pkg, ob, engine):
 def test_gpu_noma_activation_table_device_vs_host(pkg, engine):
     """activeUE on the device (noma_activation_kernel, NOMA.c:131-192) against the host form built with the reference's libm:
     preamble, sector and draw count of EVERY UE identical; the gain of a UE the kernel did not flag within 32 ulp of the host's (the
-    resolver's comparison band is ~90 ulp), of a flagged UE the host's bits (recomputed); few UEs flagged (the expected rate is
+    resolver's order band ACT_GAIN_ORDER_BAND = 4e-14 relative = 180 ulp covers two such gains off in opposite directions: prach_noma_act.h), of a flagged UE the host's bits (recomputed); few UEs flagged (the expected rate is
     3 x 128 / 2^29 = 7e-7: float rounding boundaries of x, y and the path loss)."""
     nflag = ntot = 0
     worst = 0

@@ -1,5 +1,5 @@
 """Development probe: the bench's single trial (BASELINE config 2) under engine options. Not a test.
-usage: gpu_single.py "cluster=32,lds_records=1;cluster=16;lds_records=0" [variant] [nUE] [check]"""
+usage: gpu_single.py "cluster=32,lds_records=1;cluster=16;lds_records=0" [variant] [nUE] [check|-] [glibc]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -9,10 +9,11 @@ eng = m.Engine(0)
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 nUE = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 check = len(sys.argv) > 4 and sys.argv[4] == "check"
+rng = m.RNG_GLIBC if len(sys.argv) > 5 and sys.argv[5] == "glibc" else m.RNG_PHILOX
 ref = None
 if check:
     from oracle import binding as ob
-    ref, _ = ob.run_trial(ob.make_cfg(nUE, variant=variant), ob.Rng(ob.RNG_PHILOX, 0), want_ues=False)
+    ref, _ = ob.run_trial(ob.make_cfg(nUE, variant=variant), ob.Rng(ob.RNG_GLIBC if rng == m.RNG_GLIBC else ob.RNG_PHILOX, 0), want_ues=False)
 DEFAULTS = dict(cluster=0, lds_records=1, pipeline=1, dense=0, fast=1)
 for spec in sys.argv[1].split(";"):
     opts = dict(DEFAULTS)
@@ -21,7 +22,7 @@ for spec in sys.argv[1].split(";"):
         opts[k] = int(v)
     for k, v in opts.items():
         eng.set(k, v)
-    cfg = m.make_cfg(nUE, variant=variant, rng_mode=m.RNG_PHILOX, seed=0)
+    cfg = m.make_cfg(nUE, variant=variant, rng_mode=rng, seed=0)
     best = 1e9
     for rep in range(3):
         (r,), _ = eng.run_trials([cfg])
