@@ -1,28 +1,30 @@
 // prach_batch.hip — the BATCHED regime: one workgroup per trial, thousands of trials in flight (BASELINE configs[2] / [4]: the
-// --times x nUE sweep).  The state of the in-flight trials streams through HBM every subframe, so what a UE costs per subframe is
-// what the pass READS of it and how many instructions the pass spends on it.
+// --times x nUE sweep).  The state of the in-flight trials streams through HBM every subframe, so what a UE costs is what is READ of it
+// and how many instructions are spent on it — in every subframe it merely waits in.
 //
-// Measured on prach::cluster_kernel's 8 + 4 byte form (round 3, diagnostic stamps, one 100 000-UE trial per workgroup): 79 % of a
-// subframe is the walk over the hot records, and that walk is bound by SCALAR instruction issue — ~55 scalar + ~45 vector
-// instructions per 64-UE visit, one scalar instruction per 4 cycles per SIMD: 92 k of 117 k cycles.  Hence this kernel:
-//
-//   * The walk reads ONE 32-bit PASS WORD per UE and nothing else:
-//         [15:0] tj   subframe from which the UE is matched by preambleCollision scans (its txTime)         0xFFFF: never
-//         [21:16] dur number of subframes it then contends with its RAR window open (Beta.c:245): matched in [tj, tj + dur)
-//         [29:24] preamble       [30] finished for good       [31] UL grant (set by the resolver with one atomicOr)
-//     (prach_ue_body.h: pw_make / pw_catch_up / pw_schedule).  A UE in steady contention is bumped every subframe (Beta.c:346,358) and counts one RAR-window subframe each time, so its
-//     whole trajectory until the window closes is known when it is scheduled: the walk only adds it to its bucket's histogram
-//     and keeps the bucket's lowest index (two LDS atomics), branch-free, and never writes.  A UE whose time has come
-//     (t == tj + dur: window expiry, Msg3, a deferred outcome) or that got a grant is an EVENT: its index goes to a queue.
-//   * Everything else about a UE — the 16-byte hot record of prach_device.h plus draw index, preambleTxCounter, failCount,
-//     first / second TxTime — is ONE 32-byte record, read and written only by the event body: an event is one 32-byte sector
-//     in, one out, plus the pass word (the general kernel touched up to seven arrays per event; profiles/r03_config3.md).
+// Round 3 walked one 32-bit pass word per live UE per subframe (79 % -> 30 % of a subframe; profiles/r03_config3.md).  Round 4: NO WALK.
+// A UE in steady contention is bumped every subframe (Beta.c:346,358) and counts one RAR-window subframe each time (Beta.c:245), so when the
+// event body schedules a UE its whole trajectory until its next event is known: matched by preambleCollision scans in [tj, tj + dur), an
+// event at tj + dur (prach_ue_body.h: pw_schedule).  The trial keeps two CALENDARS (time-indexed lists in global memory, their fill counts in LDS):
+//   * the JOIN calendar: at tj the UE adds itself to the per-bucket histogram and lowest-index tables of the subframes tj .. tj + dur - 1 —
+//     a ring of HRING subframes in LDS (dur x 2 LDS atomics, ONCE per contention window instead of two per subframe of the window);
+//   * the EVENT calendar: at tj + dur (window expiry, Msg3, a deferred outcome) the UE's index is in the list of the subframe — that list IS the
+//     event queue of the subframe: complete when the subframe begins (no pass, no barrier in front of the event body), dense (64 UEs per batch).
+// What a subframe costs is therefore its EVENTS (one 32-byte record in, one out, two 4-byte calendar entries in and out), not its live UEs.
+//   * An UL grant (the resolver, Beta.c:336-347) takes a UE out of contention early: the UE goes into the next subframe's event list (bit 31),
+//     into the workgroup's granted set of this subframe (LDS bitmap + list: its other calendar entries of the next subframe are skipped, a later
+//     one is recognised by its generation count), and a granted mid-window UE — necessarily the only member of its bucket — is taken out of the
+//     ring's later subframes by the granting thread (its remaining window rides in the low bits of the lowest-index word).
+//   * Everything about a UE — the 16-byte hot record of prach_device.h plus draw index, preambleTxCounter, failCount, first / second TxTime, the
+//     schedule word — is ONE 32-byte record, read and written only by the event body.
 //   * The event body is prach_ue_body.h (shared with every other kernel); the resolver is prach_cluster.hip's for one workgroup.
-//   * No per-subframe capacity on the event queue or on the resolver's event list: both continue in global memory behind their LDS part.
+//   * No per-subframe capacity on the resolver's event list or the leaver candidates (they continue in global memory); a calendar list holds
+//     PD->calcap entries (the engine sizes it at nUE / 4, at nUE for small trials) — beyond that the trial is rerun on trial_kernel, reported.
 //   * batch_kernel<16, true>: the same in the reference's own rand() stream (what `prach_sim -t 100` issues per sweep point) — the event body
 //     runs as a count pass + a block-wide prefix over the 64-UE groups + a select pass, see the kernel's head.
 //   * PRACH_FLAG_SECTOR_GRANTS (WithNOMA:626-637): six grant budgets in the grant phase.
-// Limits (the engine falls back to prach::cluster_kernel): nPreamble <= 64, maxRarWindow <= 64, < 65 000 subframes; the reference-stream form: 131 072 UEs.
+// Limits (the engine falls back to prach::cluster_kernel): nPreamble <= 64, maxRarWindow <= 64 (<= 16 in the two-trials-per-CU shape), < 65 000
+// subframes, backoff + accessTime + maxRarWindow + 70 <= 256 (the calendar's horizon); the reference-stream form: 131 072 UEs.
 // Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351; decomposition: DESIGN.md section 3.
 #include "prach_device.h"
 #include "prach_device_fn.h"
@@ -46,65 +48,67 @@ namespace {
 constexpr int NPB = 64;       // stride of the per-bucket tables (nPreamble <= 64)
 constexpr int BSC = 2048;     // singleton callers per subframe
 constexpr int BGB = 1024;     // grant selection bins
-constexpr int BPF = 4;        // pass words in flight per wavefront (groups fetched ahead)
-constexpr int BSTG = 64 + 64 * BPF + 64; // per-wavefront stage: event UEs collected before queue slots are taken for them (a round of BPF visits fits behind a leftover)
-constexpr int BGROUPS = 8192; // 64-UE groups per trial at most (524 288 UEs): live-group lists of BGROUPS / NWB entries per wavefront
+constexpr int CR = 256;       // calendar slots: the fill counts of the subframes t .. t + 255 (LDS); a trial uses the first calmask + 1 of them
 // Workgroup shapes.  NWB wavefronts per workgroup: 16 (1024 threads, one workgroup = one trial per CU) or 8 (512 threads and an LDS
 // footprint under 80 KB, so that TWO workgroups = two independent trials share a CU: while one waits at a barrier or for its event
-// records, the other one issues).  What is held in LDS per subframe (event list and event queue continue in global memory; the singleton
-// list BSC and the reset-cycle / crossing-bin lists RCCAP are capacities: beyond them the engine reruns the trial on trial_kernel):
+// records, the other one issues).  What is held in LDS per subframe (event list and candidate list continue in global memory; the singleton
+// list BSC, the reset-cycle / crossing-bin lists RCCAP and the granted list are capacities: beyond them the engine reruns the trial on trial_kernel):
 template <int NWB> struct BCap {
-    static constexpr int EV = NWB == 16 ? 4096 : 2048;  // events of a subframe held in LDS (more: global memory)
+    static constexpr int EV = NWB == 16 ? 4096 : 2048;    // events of a subframe held in LDS (more: global memory)
 #ifdef PRACH_QCAP
-    static constexpr int Q = PRACH_QCAP;                  // (test build: nearly every subframe's queue continues in global memory)
+    static constexpr int CAND = PRACH_QCAP;                 // (test build: nearly every subframe's candidate list continues in global memory)
 #else
-    static constexpr int Q = NWB == 16 ? 6144 : 2048;   // event queue entries held in LDS (more: global memory)
+    static constexpr int CAND = NWB == 16 ? 4096 : 2048;  // early-leaver candidates of a subframe held in LDS (more: global memory)
 #endif
-    static constexpr int LCAP = BGROUPS / NWB;            // live 64-UE groups per wavefront
+    static constexpr int HRING = NWB == 16 ? 64 : 16;     // subframes ahead the histogram / lowest-index ring holds: a window lasts maxRarWindow - 1 < HRING subframes
+    static constexpr int GBITS = NWB == 16 ? 32768 : 16384; // granted-UE bitmap (bit = UE index mod GBITS: exact below that many UEs, else a filter in front of the list)
+    static constexpr int GL = NWB == 16 ? 1024 : 512;     // granted UEs of a subframe (list)
 };
 
 constexpr int EVB_CALLER = UEV_CALLER, EVB_RESETCAND = UEV_RESETCAND, EVB_RJOIN = UEV_RJOIN, EVB_LEAVER = 4;
 
-enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_SPARE, B_NEV, B_NCAND, B_QN, B_NCROSS, B_PTC, B_FC, B_SUMT = 16, B_ND = 18,
-       B_VISITS = 20, B_EVENTS = 21, B_SGC = 24 /* [24, 30): sectorGrants[6], WithNOMA:260 (PRACH_FLAG_SECTOR_GRANTS) */ };
+// (the event / candidate / granted counts exist twice, by subframe parity: a wavefront that is already in the next subframe's body appends to the other one)
+enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_OVF /* a calendar list / the granted list is full: the trial leaves */, B_NEV = 8 /* [2] */, B_NCAND = 10 /* [2] */,
+       B_NGL = 12 /* [2] granted UEs */, B_PTC = 14, B_FC, B_SUMT = 16, B_ND = 18, B_JOINS = 20, B_EVENTS = 21, B_NCROSS = 22, B_SGC = 24 /* [24, 30): sectorGrants[6], WithNOMA:260 (PRACH_FLAG_SECTOR_GRANTS) */ };
 
 // ---- LDS layout: byte offsets, all compile-time ------------------------------------------------------------------------------------
 template <int NWB> struct BL {
     using C = BCap<NWB>;
     static constexpr int GEV = 0;                          // int2 [EV] events of this subframe
-    static constexpr int SIDX = GEV + 8 * C::EV;           // int [BSC]
+    static constexpr int SIDX = GEV + 8 * C::EV;           // int [BSC] singleton callers: index | bucket << 20
     static constexpr int RCL = SIDX + 4 * BSC;             // int [RCCAP]
     static constexpr int SCAL = RCL + 4 * RCCAP;           // int [64]
     static constexpr int BINS = SCAL + 4 * 64;             // int [BGB]
     static constexpr int WTOT = BINS + 4 * BGB;            // int [16]
-    // histogram and lowest index per bucket, each followed by 64 per-lane dummy words: a lane that is not matched adds to / takes the
-    // minimum of its own dummy word, so the walk issues both atomics unconditionally (no exec-mask branch)
-    static constexpr int HISTX = WTOT + 4 * 16;            // int [NPB + 64]
-    static constexpr int MLOCX = HISTX + 4 * (NPB + 64);   // int [NPB + 64]
-    static constexpr int TOTAL = MLOCX + 4 * (NPB + 64);   // int [NPB]
+    static constexpr int TOTAL = WTOT + 4 * 16;            // int [NPB]
     static constexpr int FCALL = TOTAL + 4 * NPB;          // int [2][NPB] by subframe parity
     static constexpr int LCALL = FCALL + 8 * NPB;          // int [2][NPB]
     static constexpr int NLV = LCALL + 8 * NPB;            // int [NPB]
     static constexpr int FIE = NLV + 4 * NPB;              // int [NPB]
-    static constexpr int LIST = FIE + 4 * NPB;             // unsigned short [NWB][LCAP + 4 * BPF]: per wavefront, the 64-UE groups it still has to look at
-    static constexpr int QUEUE = LIST + 2 * NWB * (C::LCAP + 4 * BPF); // int [Q]
-    static constexpr int STAGE = QUEUE + 4 * C::Q;         // int [NWB][BSTG + 64]: stage, then 64 per-lane dummy words (a lane without an event writes there)
-    static constexpr int END = STAGE + 4 * NWB * (BSTG + 64);
-    static_assert(SIDX % 16 == 0 && LIST % 16 == 0 && (2 * (C::LCAP + 4 * BPF)) % 16 == 0, "alignment");
+    static constexpr int FMINP = FIE + 4 * NPB;            // int [NPB] the lowest matched UE of every bucket as the ring held it: index << 6 | subframes of its window still ahead
+    static constexpr int HR = FMINP + 4 * NPB;             // int [HRING][NPB] histogram ring: matched UEs per bucket in the subframes t .. t + HRING - 1 (slot = subframe mod HRING)
+    static constexpr int MR = HR + 4 * C::HRING * NPB;     // int [HRING][NPB] lowest matched index << 6 | remaining window, same ring
+    static constexpr int ECNT = MR + 4 * C::HRING * NPB;   // int [CR] entries in the event calendar's list of the subframes t .. (slot = subframe & calmask)
+    static constexpr int JCNT = ECNT + 4 * CR;             // int [CR] ... in the join calendar's
+    static constexpr int GBM = JCNT + 4 * CR;              // unsigned [2][GBITS / 32] granted-UE bitmap, by subframe parity
+    static constexpr int GLIST = GBM + 2 * C::GBITS / 8;   // int [2][GL] granted UEs, by subframe parity
+    static constexpr int CANDL = GLIST + 2 * 4 * C::GL;    // int [CAND] early-leaver candidates: index | old bucket << 20
+    static constexpr int END = CANDL + 4 * C::CAND;
+    static_assert(SIDX % 16 == 0 && HR % 16 == 0, "alignment");
 };
 static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
 // The reference's own rand() stream (GLIBC instantiation, 1024 threads): per 64-UE group of the trial, the lanes that make at least one / two rand()
 // calls in this subframe (two 64-bit masks) and the group's exclusive prefix of calls in index order.  BGG groups = 131 072 UEs at most.
 constexpr int BGG = 2048;
-struct BLG { static constexpr int GM = BL<16>::END, GPRE = GM + 16 * BGG, END = GPRE + 4 * BGG; };
+struct BLG { static constexpr int GM = (BL<16>::END + 15) / 16 * 16, GPRE = GM + 16 * BGG, END = GPRE + 4 * BGG; };
 static_assert(BLG::END <= 160 * 1024 && BLG::GM % 16 == 0, "LDS");
 
 #define BI(off) (reinterpret_cast<int *>(smem + (off)))
 #define BU(off) (reinterpret_cast<unsigned *>(smem + (off)))
 #define BI2(off) (reinterpret_cast<int2 *>(smem + (off)))
 
-// the 32-byte event record: A = the hot record of prach_device.h {txTime, timer base, nowBackoff, packed}; B = {Philox draw index,
-// preambleTxCounter | failCount << 16, secondTxTime | firstTxTime << 16, the pass word it was scheduled with}
+// the 32-byte event record: A = the hot record of prach_device.h {txTime, timer base, nowBackoff, packed}; B = {Philox draw index (24 bits) |
+// generation count of the UE's schedule << 24, preambleTxCounter | failCount << 16, secondTxTime | firstTxTime << 16, the schedule word}
 struct BRec { int4 a, b; };
 __device__ __forceinline__ BRec brec_load(const PRACH_G v4i_t *p) {
     const v4i_t a = p[0], b = p[1]; // (plain loads and stores: non-temporal ones cost 30 % on config 3 — a record's line is read again soon)
@@ -122,9 +126,12 @@ __device__ __forceinline__ ColdRegs cold_unpack(const int4 b) {
     c.ptc = b.y & 0xffff; c.fcnt = (int)((unsigned)b.y >> 16); c.stt = b.z & 0xffff; c.ftt = (int)((unsigned)b.z >> 16);
     return c;
 }
-__device__ __forceinline__ int4 cold_pack(const unsigned nd, const ColdRegs &c, const unsigned word) {
-    return make_int4((int)nd, (c.ptc & 0xffff) | (c.fcnt << 16), (c.stt & 0xffff) | (c.ftt << 16), (int)word);
+__device__ __forceinline__ int4 cold_pack(const unsigned nd, const unsigned gen, const ColdRegs &c, const unsigned word) {
+    return make_int4((int)((nd & 0xFFFFFFu) | (gen << 24)), (c.ptc & 0xffff) | (c.fcnt << 16), (c.stt & 0xffff) | (c.ftt << 16), (int)word);
 }
+// calendar entries.  Event calendar: UE index [19:0] | generation [27:20] | bit 31: an UL grant of the previous subframe (always valid).
+// Join calendar: UE index [19:0] | bucket [25:20] | window length [31:26].
+constexpr int CAL_GRANT = (int)0x80000000u;
 
 } // namespace
 
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     static_assert(!GLIBC || NWB == 16, "the reference-stream form exists in the 1024-thread shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using bl = BL<NWB>;
-    constexpr int TB = NWB * 64, BEV = BCap<NWB>::EV, BQ = BCap<NWB>::Q, BLCAP = BCap<NWB>::LCAP;
+    constexpr int TB = NWB * 64, BEV = BCap<NWB>::EV, CCAP = BCap<NWB>::CAND, HRING = BCap<NWB>::HRING, GBITS = BCap<NWB>::GBITS, GLCAP = BCap<NWB>::GL;
     const TrialDev *const PD = params + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nUE = PD->nUE, nP = PD->nP, aT = PD->aT, stop = PD->stop, nGrantUL = PD->nGrantUL, binshift = PD->binshift;
@@ -150,9 +157,11 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     K.fmP = make_fastmod(nP); K.fmB = make_fastmod(PD->backoff); K.fmA = make_fastmod(aT); K.fm5 = make_fastmod(5);
     const bool withnoma = K.withnoma;
     PRACH_G v4i_t *const rec32 = (PRACH_G v4i_t *)PD->rec32;     // [nUE][2]
-    PRACH_G unsigned *const pw = (PRACH_G unsigned *)PD->pw;     // [whole groups] pass words
-    PRACH_G int *const qov = (PRACH_G int *)PD->qov;             // [nUE] event queue beyond its LDS part
-    PRACH_G v2i_t *const cand = (PRACH_G v2i_t *)PD->cand;       // early-leaver candidates of a subframe
+    PRACH_G int *const ecal = (PRACH_G int *)PD->ecal;           // [calmask + 1][calcap] event calendar
+    PRACH_G int *const jcal = (PRACH_G int *)PD->jcal;           // [calmask + 1][calcap] join calendar
+    const int calcap = PD->calcap;
+    const unsigned calmask = (unsigned)PD->calmask;
+    PRACH_G int *const candg = (PRACH_G int *)PD->qov;           // [nUE] early-leaver candidates of a subframe beyond their LDS part
     const PRACH_G int *const sched = (const PRACH_G int *)PD->sched;
     int *const scal = BI(bl::SCAL);
     int2 *const gev = BI2(bl::GEV);
@@ -161,10 +170,9 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     auto ev_get = [&](const int k) -> int2 { if (k < BEV) return gev[k]; const v2i_t v = evov[k - BEV]; return make_int2(v.x, v.y); };
     auto ev_set = [&](const int k, const int a, const int b) { if (k < BEV) gev[k] = make_int2(a, b); else store_i2(&evov[k - BEV], a, b); };
     auto ev_kill = [&](const int k) { if (k < BEV) gev[k].y = 0; else evov[k - BEV].y = 0; };
-    int *const queue = BI(bl::QUEUE);
-    unsigned short *const lst = reinterpret_cast<unsigned short *>(smem + bl::LIST) + w * (BLCAP + 4 * BPF); // this wavefront's live groups
-    int *const histx = BI(bl::HISTX), *const mlocx = BI(bl::MLOCX);
-    int *const stage = BI(bl::STAGE) + w * (BSTG + 64);
+    int *const ecnt = BI(bl::ECNT), *const jcnt = BI(bl::JCNT);
+    int *const hr = BI(bl::HR), *const mr = BI(bl::MR);
+    int *const candl = BI(bl::CANDL);
     unsigned *const gm = BU(BLG::GM);  // (GLIBC only) [BGG][4]: lanes with >= 1 call (two words), lanes with 2 calls (two words)
     int *const gpre = BI(BLG::GPRE);   // (GLIBC only) [BGG]
     const PRACH_G int *const stream = (const PRACH_G int *)PD->stream;
@@ -173,27 +181,38 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
 
     const int totgroups = (nUE + 63) >> 6;
     // calloc + initialUE (Beta.c:78-83)
-    for (int i = tid; i < (totgroups + 1) * 64; i += TB) {
-        if (i < nUE) brec_store(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0), make_int4(0, 0, 0, (int)PW_IDLE));
-        pw[i] = i < nUE ? PW_IDLE : PW_DONE; // (padded to whole 64-UE groups, plus the padding group the list's empty entries point at)
-    }
+    for (int i = tid; i < nUE; i += TB) brec_store(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0), make_int4(0, 0, 0, (int)PW_IDLE));
+    for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; }
+    for (int k = tid; k < CR; k += TB) { ecnt[k] = 0; jcnt[k] = 0; }
+    for (int k = tid; k < 2 * GBITS / 32; k += TB) BU(bl::GBM)[k] = 0u;
     if (tid < NPB) {
-        BI(bl::HISTX)[tid] = 0; BI(bl::MLOCX)[tid] = INT_MAX; BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0;
+        BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; BI(bl::FMINP)[tid] = INT_MAX;
         BI(bl::FCALL)[tid] = INT_MAX; BI(bl::FCALL)[NPB + tid] = INT_MAX; BI(bl::LCALL)[tid] = -1; BI(bl::LCALL)[NPB + tid] = -1;
     }
     if (tid < 64) scal[tid] = 0;
     if (GLIBC) for (int k = tid; k < 4 * BGG; k += TB) gm[k] = 0u;
-    if (lane < 4 * BPF) lst[lane] = (unsigned short)totgroups; // empty list: padding entries only
     __syncthreads();
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
-    int nlive = 0; // entries of this wavefront's list (wave-uniform)
+    int acNext = sched[0]; // the arrival table's entry of the NEXT access slot: loaded a slot ahead, so that no subframe waits for it (Beta.c:121-134)
     int why = 0;   // which per-subframe capacity ended the trial (reported)
     unsigned long long steps = 0;
-    int status = (nP > NPB || K.maxRar > 64 || stop > 65000 || totgroups > (GLIBC ? BGG : BGROUPS) || nUE >= (1 << 20)) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
+    int status = (nP > NPB || K.maxRar > HRING || stop > 65000 || (GLIBC && totgroups > BGG) || nUE >= (1 << 20) || calmask >= (unsigned)CR ||
+                  PD->backoff + max(aT, 5) + K.maxRar + 70 > (int)calmask + 1) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
 #ifdef PRACH_STAMPS
     unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
 #endif
+    // was UE i given an UL grant in the subframe whose granted set sits at parity `par`?  (bitmap first; exact list behind it when the trial has more UEs than bits)
+    auto granted_in = [&](const int par, const int i) -> bool {
+        const unsigned *const bm = BU(bl::GBM) + par * (GBITS / 32);
+        if (!((bm[(i & (GBITS - 1)) >> 5] >> (i & 31)) & 1u)) return false;
+        if (nUE <= GBITS) return true;
+        const int n = min(scal[B_NGL + par], GLCAP);
+        const int *const gl = BI(bl::GLIST) + par * GLCAP;
+        bool hit = false;
+        for (int k = 0; k < n; k++) hit = hit || gl[k] == i;
+        return hit;
+    };
 
     for (int t = 0; t < stop && status == PRACH_OK; t++) {
         steps++;
@@ -203,121 +222,40 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             if (sectors && tid < 6) scal[B_SGC + tid] = 0; // (barriers follow before the grant phase reads them)
         }
         const int prevAC = activeCheck;
-        if (t % aT == 0 && activeCheck != nUE) activeCheck = sched[t / aT]; // Beta.c:121-134
+        if (t % aT == 0) { // Beta.c:121-134
+            if (activeCheck != nUE) activeCheck = acNext;
+            acNext = sched[t / aT + 1]; // (the table has maxTime / accessTime + 2 entries: prach_engine.hip)
+        }
         const int parity = t & 1;
         int *const fcallA = BI(bl::FCALL) + parity * NPB, *const lcallA = BI(bl::LCALL) + parity * NPB;
         int *const fcallB = BI(bl::FCALL) + (parity ^ 1) * NPB, *const lcallB = BI(bl::LCALL) + (parity ^ 1) * NPB;
+        const int slot = (int)((unsigned)t & calmask);                       // this subframe's calendar lists
+        int *const histx = hr + (t & (HRING - 1)) * NPB, *const mlocx = mr + (t & (HRING - 1)) * NPB; // ... and its histogram / lowest matched index << 6 | window left
+        const int ne = ecnt[slot], nj = jcnt[slot];                           // complete: every entry was made in an earlier subframe (the grants' behind S6)
+        const int qn = ne + (activeCheck - prevAC);                           // this access slot's arrivals (Beta.c:136-146) are events too: virtual entries behind the list's
         BSTAMP(0); // loop head
 
-        // ================= the walk: one pass word per UE =================
-        {
-            int sc = 0; // staged event UEs of this wavefront (wave-uniform)
-            auto flush = [&]() __attribute__((always_inline)) { // the stage goes to the event queue in one piece: one returning LDS atomic per ~100 event UEs
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&scal[B_QN], sc);
-                base = __builtin_amdgcn_readfirstlane(base);
-                for (int o = 0; o < sc; o += 64) {
-                    if (o + lane < sc) {
-                        const int e = stage[o + lane], q = base + o + lane;
-                        if (q < BQ) queue[q] = e; else qov[q - BQ] = e;
-                    }
-                }
-                sc = 0;
-            };
-            if (w == NWB - 1 && activeCheck > prevAC) { // this access slot's arrivals (Beta.c:136-146) are events
-                for (int i0 = prevAC; i0 < activeCheck; i0 += 64) {
-                    if (i0 + lane < activeCheck) stage[sc + lane] = i0 + lane;
-                    sc += min(64, activeCheck - i0);
-                    if (sc > BSTG - 64 * BPF) flush();
+        // ================= joins: UEs whose contention window opens in this subframe enter the ring's subframes t .. t + dur - 1 =================
+        for (int q0 = (NWB - 1 - w) * 64; q0 < nj; q0 += NWB * 64) { // (from the last wavefront down: the first ones have the most event batches)
+            const int q = q0 + lane;
+            int je = 0;
+            if (q < nj) je = jcal[(size_t)slot * (size_t)calcap + (size_t)q];
+            const int i = je & 0xFFFFF, p = (je >> 20) & 63;
+            int dur = (int)((unsigned)je >> 26);
+            if (q >= nj || granted_in(parity ^ 1, i)) dur = 0; // (granted in the subframe before: out of contention, Beta.c:338-343)
+            const int dmax = wave_max(dur);
+            for (int k = 0; k < dmax; k++) {
+                if (k < dur) {
+                    const int rs = ((t + k) & (HRING - 1)) * NPB + p;
+                    atomicAdd(&hr[rs], 1);
+                    atomicMin(&mr[rs], (i << 6) | (dur - 1 - k));
                 }
             }
-            // groups the arrival front has reached since the last subframe join this wavefront's list (group g belongs to wavefront g % NWB)
-            {
-                const int g0 = (prevAC + 63) >> 6, g1 = (activeCheck + 63) >> 6;
-                if (g1 > g0) {
-                    int g = g0 + ((w - g0) & (NWB - 1));
-                    const int before = nlive;
-                    for (; g < g1 && nlive < BLCAP; g += NWB) { if (lane == 0) lst[nlive] = (unsigned short)g; nlive++; } // (totgroups <= NWB * BLCAP: checked above)
-                    if (nlive != before && lane < 3 * BPF) lst[nlive + lane] = (unsigned short)totgroups; // behind the last entry: the padding group (finished words)
-                }
-            }
-            const bool retire = (t & 7) == (w & 7); // finished groups are looked for every 8th subframe (wave-uniform)
-            int nnull = 0;                            // list entries found finished in this subframe
-            // One 64-UE group: matched UEs go to their bucket's histogram / lowest index (Beta.c:321-330 sees them), UEs whose time has come
-            // onto the stage; every other lane hits its own dummy word — no exec-mask branch.  g: the group (same value in every lane).
-            auto visit = [&](auto RETIRE, const unsigned g, const unsigned uw, const int k) __attribute__((always_inline)) {
-                const int i = (int)(g * 64u) + lane;
-                const int dd = t - (int)(uw & 0xFFFFu);
-                const int dur = (int)((uw >> 16) & 0x3Fu);
-                const unsigned long long mGrant = __ballot((int)uw < 0);
-                const unsigned long long mMember = __ballot((unsigned)dd < (unsigned)dur) & ~mGrant;
-                const unsigned long long mHeavy = __ballot(dd >= dur) | mGrant; // (never / not yet arrived / padding: tj = 0xFFFF)
-                const bool member = __builtin_amdgcn_inverse_ballot_w64(mMember), heavy = __builtin_amdgcn_inverse_ballot_w64(mHeavy);
-                const int bx = member ? (int)((uw >> 24) & 0x3Fu) : NPB + lane;
-                atomicAdd(&histx[bx], 1);
-                atomicMin(&mlocx[bx], i);
-                int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mHeavy >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mHeavy, (unsigned)sc)); // sc + rank among the event lanes
-                asm volatile("" : "+v"(slot)); // (computed for every lane: two VALU instructions are cheaper than the exec-mask branch the compiler wraps them in)
-                stage[heavy ? slot : BSTG + lane] = i | (int)(uw & PW_GRANT);
-                sc += __builtin_amdgcn_readfirstlane(__popcll(mHeavy));
-                if (decltype(RETIRE)::value) { // (only the walk of every 8th subframe is compiled with this)
-                    if ((mMember | mHeavy) == 0ull && __ballot((uw & 0x40000000u) != 0u) == ~0ull && g != (unsigned)totgroups) {
-                        if (lane == 0) lst[k] = (unsigned short)totgroups; // every UE of the group has finished: the entry becomes padding
-                        nnull++;
-                    }
-                }
-            };
-            // Software pipeline over the list, BPF groups per round: the entries of round r + 2 are read from LDS (one ds_read_b64, the same
-            // address in every lane), the pass words of round r + 1 are in flight, round r is worked on.  The list ends with >= 3 * BPF - 1 padding entries.
-            struct alignas(2 * BPF) Ent { unsigned v[BPF / 2]; }; // BPF 16-bit entries: one ds_read_b64 / b128
-            auto ld_ent = [&](const int k) -> Ent { return *reinterpret_cast<const Ent *>(lst + k); };
-            auto ent = [&](const Ent &E, const int d) -> unsigned { return (d & 1) ? (E.v[d >> 1] >> 16) : (E.v[d >> 1] & 0xFFFFu); };
-            // (unconditional loads of mapped memory — the array is padded by one group of "finished" words.  A relaxed agent-scope load =
-            //  global_load_dword ... sc1: served by L2, never by this CU's L1, because the grant bit is set by an L2 atomic.  NOT a
-            //  non-temporal load: the words are read again every subframe, and marked streaming they lose their place in L2 / the
-            //  Infinity Cache to the event records — measured 905 -> 827 ms on config 3, 398 -> 374 / 366 -> 310 ms on 1000 Beta.c trials)
-            auto ld_pw = [&](const unsigned g) -> unsigned { return __hip_atomic_load(pw + (g * 64u + (unsigned)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-            const int npad = (nlive + BPF - 1) & ~(BPF - 1);
-            auto walk = [&](auto RETIRE) __attribute__((always_inline)) {
-                Ent E0 = ld_ent(0), E1 = ld_ent(BPF);
-                unsigned W0[BPF];
-#pragma unroll
-                for (int d = 0; d < BPF; d++) W0[d] = ld_pw(ent(E0, d));
-                for (int k = 0; k < npad; k += BPF) {
-                    const Ent E2 = ld_ent(k + 2 * BPF);
-                    unsigned W1[BPF];
-#pragma unroll
-                    for (int d = 0; d < BPF; d++) W1[d] = ld_pw(ent(E1, d));
-#pragma unroll
-                    for (int d = 0; d < BPF; d++) visit(RETIRE, ent(E0, d), W0[d], k + d);
-#pragma unroll
-                    for (int d = 0; d < BPF; d++) W0[d] = W1[d];
-                    E0 = E1; E1 = E2;
-                    if (sc > BSTG - 64 * BPF) flush(); // (the ONE place the walk empties its stage)
-                }
-            };
-            if (retire) walk(std::true_type{}); else walk(std::false_type{});
-            if (sc > 0) flush();
-            if (nnull > 0) { // (rare: a group dies once per trial) squeeze the finished entries out of the list
-                int out = 0;
-                for (int base = 0; base < nlive; base += 64) {
-                    const bool in = base + lane < nlive;
-                    const unsigned short e = in ? lst[base + lane] : (unsigned short)totgroups;
-                    const unsigned long long km = __ballot(in && e != (unsigned short)totgroups);
-                    if ((km >> lane) & 1ull) lst[out + __popcll(km & lanemask_lt(lane))] = e;
-                    out += __popcll(km);
-                }
-                nlive = out;
-                if (lane < 3 * BPF) lst[nlive + lane] = (unsigned short)totgroups;
-            }
-            if (lane == 0 && npad) atomicAdd(&scal[B_VISITS], npad); // (reported, never read by the simulation)
         }
-        BSTAMP(1); // walk
-        __syncthreads(); // the queue is complete
+        BSTAMP(1); // joins
         BSTAMP(2);
 
-        // ================= the event body: queued UEs, 64 at a time =================
-        const int qn = scal[B_QN];
+        // ================= the event body: this subframe's event list, 64 UEs at a time =================
         {
             int c_succ = 0, c_contf = 0;
             const int tmod = t % aT;
@@ -328,8 +266,8 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 const int q = q0 + lane;
                 B.v = q < qn;
                 B.e = 0;
-                if (B.v) B.e = q < BQ ? queue[q] : qov[q - BQ];
-                B.R = brec_load(rec32 + 2 * (size_t)(B.e & 0x7FFFFFFF));
+                if (B.v) B.e = q < ne ? ecal[(size_t)slot * (size_t)calcap + (size_t)q] : prevAC + (q - ne);
+                B.R = brec_load(rec32 + 2 * (size_t)(B.e & 0xFFFFF));
                 return B;
             };
             // MODE 0: Philox, everything in one pass.  MODE 1 (GLIBC): the count pass — nothing is stored but the calling lanes.  MODE 2 (GLIBC): the full
@@ -340,17 +278,22 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 for (int q0 = w * 64; q0 < qn; q0 += NWB * 64) {
                     const Batch Bc = Bn;
                     if (q0 + NWB * 64 < qn) Bn = fetch_batch(q0 + NWB * 64); // in flight while this batch is worked on
-                    const bool v = Bc.v;
                     const int e = Bc.e;
-                    const int i = e & 0x7FFFFFFF;
+                    const int i = e & 0xFFFFF;
                     const bool granted = e < 0;
+                    const bool arrival = q0 + lane >= ne;
                     BRec R = Bc.R;
+                    const unsigned gen = (unsigned)R.b.x >> 24;
+                    // An entry counts if it is the UE's current one: a grant entry always; any other one not when the UE was granted in the subframe before (its
+                    // grant entry does the work) and not when the UE has been rescheduled since the entry was made (a grant took it out of its window early)
+                    bool v = Bc.v;
+                    if (v && !granted && !arrival) v = (unsigned)((e >> 20) & 0xFF) == gen && !granted_in(parity ^ 1, i);
                     if (!v) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
                     UeState u = unpack(R.a);
                     ColdRegs cold = cold_unpack(R.b);
-                    unsigned nd = (unsigned)R.b.x;
+                    unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
                     if (v) pw_catch_up(u, (unsigned)R.b.w, granted, i, t, K.fmA, tab);
-                    if (v && i >= prevAC && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
+                    if (v && arrival && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
                         ue_activate(u, i, t, cold);
                         if (withnoma) nd = 2;
                         // the reference's stream has no per-UE draw index: the record's word keeps the UE's sector instead, fixed by the first of its two
@@ -381,30 +324,45 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                         nd += (unsigned)pl.need;
                     }
                     const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
-                    // ---- bucket bookkeeping ----
+                    // ---- bucket bookkeeping (this subframe's ring slot; an event UE has nothing in the later ones: window left = 0) ----
                     if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
-                    if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i);
-                    if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i);
+                    if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i << 6);
+                    if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i << 6);
                     {
                         const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(o.eclass);
                         if (em | cm) {
                             int b_ev = 0, b_cd = 0;
                             if (lane == 0) {
-                                if (em) b_ev = atomicAdd(&scal[B_NEV], __popcll(em));
-                                if (cm) b_cd = atomicAdd(&scal[B_NCAND], __popcll(cm));
+                                if (em) b_ev = atomicAdd(&scal[B_NEV + parity], __popcll(em));
+                                if (cm) b_cd = atomicAdd(&scal[B_NCAND + parity], __popcll(cm));
                             }
                             b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
                             if (o.evtype != UEV_NONE) {
                                 const int es = b_ev + __popcll(em & lanemask_lt(lane));
                                 ev_set(es, i, ue_event_info(o));
                             }
-                            if (o.eclass) store_i2(&cand[b_cd + __popcll(cm & lanemask_lt(lane))], i, o.oldp);
+                            if (o.eclass) {
+                                const int cs = b_cd + __popcll(cm & lanemask_lt(lane)), cv = i | (o.oldp << 20);
+                                if (cs < CCAP) candl[cs] = cv; else candg[cs - CCAP] = cv;
+                            }
                         }
                     }
                     if (v) {
+                        // the UE's schedule from here (prach_ue_body.h): matched in [tj, tj + dur), its next event at tj + dur — into the calendars
                         const unsigned word = pw_schedule<false>(u, t, K.maxRar);
-                        brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, cold, word));
-                        pw[i] = word;
+                        const unsigned gen1 = (gen + 1u) & 0xFFu;
+                        brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, gen1, cold, word));
+                        const unsigned tjn = word & 0xFFFFu, durn = (word >> 16) & 0x3Fu;
+                        if (tjn != 0xFFFFu) { // (0xFFFF: finished for good, or a txTime that never comes — Beta.c:167)
+                            if (durn > 0u) {
+                                const int js = (int)(tjn & calmask), jp = atomicAdd(&jcnt[js], 1);
+                                if (jp < calcap) jcal[(size_t)js * (size_t)calcap + (size_t)jp] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
+                                else scal[B_OVF] = 1;
+                            }
+                            const int es_ = (int)((tjn + durn) & calmask), ep = atomicAdd(&ecnt[es_], 1);
+                            if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)ep] = (int)((unsigned)i | (gen1 << 20));
+                            else scal[B_OVF] = 1;
+                        }
                     }
                 }
             };
@@ -447,40 +405,54 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             }
         }
         BSTAMP(3); // event body
-        __syncthreads(); // S1: histogram / lowest callers / candidate list are complete; the caller tables of t - 1 are free
+        __syncthreads(); // S1: histogram / lowest callers / candidate list are complete; the caller tables of t - 1 and the granted set of t - 1 are free
         BSTAMP(4);
 
         // early leavers below the bucket's lowest caller are the only ones a rank can need
         {
-            const int ncand = scal[B_NCAND];
-            for (int k = tid; k < ncand; k += TB) {
-                const v2i_t c = cand[k];
-                if (c.x < mlocx[c.y]) {
-                    const int es = atomicAdd(&scal[B_NEV], 1);
-                    ev_set(es, c.x, EVB_LEAVER | (c.y << 4));
+            const int ncand = scal[B_NCAND + parity];
+            for (int k0 = w * 64; k0 < ncand; k0 += TB) {
+                const int k = k0 + lane;
+                const int c = k < ncand ? (k < CCAP ? candl[k] : candg[k - CCAP]) : 0;
+                const int ci = c & 0xFFFFF, cp = (c >> 20) & 63;
+                const unsigned long long lm = __ballot(k < ncand && ci < (mlocx[cp] >> 6));
+                if (lm) {
+                    int b_ev = 0;
+                    if (lane == 0) b_ev = atomicAdd(&scal[B_NEV + parity], __popcll(lm));
+                    b_ev = __builtin_amdgcn_readfirstlane(b_ev);
+                    if ((lm >> lane) & 1ull) ev_set(b_ev + __popcll(lm & lanemask_lt(lane)), ci, EVB_LEAVER | (cp << 4));
                 }
             }
-            if (GLIBC) // every draw of this subframe has been read: the marks of the groups the queued UEs are in can go
+            if (GLIBC) // every draw of this subframe has been read: the marks of the groups the event UEs are in can go
                 for (int q = tid; q < qn; q += TB) {
-                    const int e = q < BQ ? queue[q] : qov[q - BQ];
-                    *reinterpret_cast<uint4 *>(&gm[4 * ((e & 0x7FFFFFFF) >> 6)]) = make_uint4(0u, 0u, 0u, 0u);
+                    const int i = q < ne ? (ecal[(size_t)slot * (size_t)calcap + (size_t)q] & 0xFFFFF) : prevAC + (q - ne);
+                    *reinterpret_cast<uint4 *>(&gm[4 * (i >> 6)]) = make_uint4(0u, 0u, 0u, 0u);
                 }
-            if (tid < NPB) { lcallB[tid] = -1; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; }
+            { // the granted set of subframe t - 1 has been used by every join and every event of this subframe: empty it (bit by bit, from its list)
+                const int par = parity ^ 1;
+                const int n = min(scal[B_NGL + par], GLCAP);
+                unsigned *const bm = BU(bl::GBM) + par * (GBITS / 32);
+                const int *const gl = BI(bl::GLIST) + par * GLCAP;
+                for (int k = tid; k < n; k += TB) bm[(gl[k] & (GBITS - 1)) >> 5] = 0u;
+            }
+            if (tid < NPB) { // this workgroup's histogram / lowest callers ARE the totals (only read here: the filter above reads them too)
+                lcallB[tid] = -1; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0;
+                const int m_ = mlocx[tid];
+                BI(bl::TOTAL)[tid] = histx[tid]; fcallA[tid] = m_ == INT_MAX ? INT_MAX : (m_ >> 6); BI(bl::FMINP)[tid] = m_;
+            }
             if (tid == 0) {
-                scal[B_EVENTS] += scal[B_QN]; // (reported, never read by the simulation)
-                scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0; scal[B_QN] = 0;
+                scal[B_EVENTS] += qn; scal[B_JOINS] += nj; // (reported, never read by the simulation)
+                scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0;
+                ecnt[slot] = 0; jcnt[slot] = 0; // (this slot is the subframe t + calmask + 1 from here on: nothing is scheduled that far ahead)
             }
         }
         BSTAMP(5); // leaver filter
         __syncthreads(); // S2
         BSTAMP(6);
-        const int N = scal[B_NEV];
-        if (tid < NPB) { // this workgroup's histogram / lowest callers ARE the totals
-            BI(bl::TOTAL)[tid] = BI(bl::HISTX)[tid]; fcallA[tid] = BI(bl::MLOCX)[tid];
-            BI(bl::HISTX)[tid] = 0; BI(bl::MLOCX)[tid] = INT_MAX;
-        }
-        __syncthreads(); // S3
-        if (tid == 0) { scal[B_NEV] = 0; scal[B_NCAND] = 0; }
+        if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = 5; time_exit = t; break; } // a calendar list (or the granted list, a subframe ago) was full
+        const int N = scal[B_NEV + parity];
+        if (tid < NPB) { histx[tid] = 0; mlocx[tid] = INT_MAX; } // (this ring slot is the subframe t + HRING from here on: joined at t + 2 at the earliest)
+        if (tid == 64) scal[B_NGL + (parity ^ 1)] = 0;
         const int nsucc_tot = scal[B_NSUCC];
         // classify the events against the lowest DEFINITE caller of every bucket
         for (int k = tid; k < N; k += TB) {
@@ -577,7 +549,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 if (lcallA[p] < idx) atomicMax(&lcallA[p], idx);
                 if (check == 1) {
                     const int s = atomicAdd(&scal[B_NS], 1);
-                    if (s < BSC) BI(bl::SIDX)[s] = idx;
+                    if (s < BSC) BI(bl::SIDX)[s] = idx | (p << 20);
                     my_txop += 1;
                 } else if (withnoma) { // WithNOMA:650-652
                     my_coll += check; my_txop += check;
@@ -593,13 +565,32 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         BSTAMP(9); // calls
         __syncthreads(); // S5: calls done; singles listed
         BSTAMP(10);
+        if (tid == 0) { scal[B_NEV + parity] = 0; scal[B_NCAND + parity] = 0; } // (every thread has read them; the next subframe appends to the other pair)
         const int ns = scal[B_NS];
         if (ns > BSC) { status = PRACH_ERR_INTERNAL; why = 3; time_exit = t; break; }
         const int Gr = max(0, nGrantUL - 1 - grantCheck); // Beta.c:336-347
-        auto grant = [&](const int my) { __hip_atomic_fetch_or(pw + my, PW_GRANT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }; // ONE fire-and-forget L2 atomic
+        // An UL grant (Beta.c:338-343) for the singleton caller `my` of bucket bp: into this subframe's granted set and the next subframe's event list; a
+        // mid-window UE (the bucket's lowest matched index as the ring held it, with subframes of its window still ahead) leaves the ring's later
+        // subframes — it was the bucket's only member, so its contributions there are exactly one count and the lowest index
+        auto grant = [&](const int my, const int bp) {
+            atomicOr(&(BU(bl::GBM) + parity * (GBITS / 32))[(my & (GBITS - 1)) >> 5], 1u << (my & 31));
+            const int gp = atomicAdd(&scal[B_NGL + parity], 1);
+            if (gp < GLCAP) (BI(bl::GLIST) + parity * GLCAP)[gp] = my; else scal[B_OVF] = 1;
+            const int es_ = (int)((unsigned)(t + 1) & calmask), ep = atomicAdd(&ecnt[es_], 1);
+            if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)ep] = my | CAL_GRANT; else scal[B_OVF] = 1;
+            const int fm = BI(bl::FMINP)[bp];
+            if ((fm >> 6) == my && fm != INT_MAX) {
+                const int rem = fm & 63;
+                for (int k = 1; k <= rem; k++) {
+                    const int rs = ((t + k) & (HRING - 1)) * NPB + bp;
+                    atomicSub(&hr[rs], 1);
+                    atomicCAS(&mr[rs], (my << 6) | (rem - k), INT_MAX);
+                }
+            }
+        };
         // a caller's sector: Philox — a function of the UE's own first activation draw, recomputed; the reference's stream — kept in the UE's record
         auto sector_of = [&](const int my) -> int {
-            if (GLIBC) return rec32[2 * (size_t)my + 1].x;
+            if (GLIBC) return rec32[2 * (size_t)my + 1].x & 0xFF;
             return sector_of_draw(philox_draw31(seed_lo, seed_hi, (unsigned)my, 0u, (unsigned)nUE, (unsigned)variant));
         };
         if (sectors) {
@@ -610,11 +601,12 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 if (tid < 64) {
                     const int nsu = __builtin_amdgcn_readfirstlane(ns);
                     const bool have = tid < nsu;
-                    const int my = have ? BI(bl::SIDX)[tid] : INT_MAX;
+                    const int sp = have ? BI(bl::SIDX)[tid] : 0;
+                    const int my = have ? (sp & 0xFFFFF) : INT_MAX;
                     const int sec = have ? sector_of(my) : 7;
                     int rank = 0;
                     for (int s_ = 0; s_ < nsu; s_++) rank += (__builtin_amdgcn_readlane(my, s_) < my && __builtin_amdgcn_readlane(sec, s_) == sec) ? 1 : 0;
-                    if (have && rank < nGrantUL - 1 - scal[B_SGC + sec]) grant(my);
+                    if (have && rank < nGrantUL - 1 - scal[B_SGC + sec]) grant(my, (sp >> 20) & 63);
                     int mine = 0;
 #pragma unroll
                     for (int s_ = 0; s_ < 6; s_++) { const int c = __popcll(__ballot(sec == s_)); mine = tid == s_ ? c : mine; }
@@ -631,9 +623,9 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 if (tid == 0) scal[B_NCROSS] = 0;
                 __syncthreads();
                 for (int j = tid; j < ns; j += TB) {
-                    const int my = sidx[j];
+                    const int sp = sidx[j], my = sp & 0xFFFFF;
                     const int sec = sector_of(my);
-                    sidx[j] = my | (sec << 24); // (UE indices have 20 bits)
+                    sidx[j] = sp | (sec << 26); // (UE indices have 20 bits, the bucket 6)
                     atomicAdd(&bins[sec * SB + (my >> shift)], 1);
                 }
                 __syncthreads();
@@ -651,24 +643,24 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 }
                 __syncthreads();
                 for (int j = tid; j < ns; j += TB) {
-                    const int e_ = sidx[j], my = e_ & 0xFFFFFF, sec = e_ >> 24;
+                    const int e_ = sidx[j], my = e_ & 0xFFFFF, sec = e_ >> 26;
                     const int bin = sec * SB + (my >> shift);
                     const int Gs = nGrantUL - 1 - scal[B_SGC + sec];
                     const int before = bins[bin] - bins[sec * SB]; // singleton callers of this sector in lower bins
                     if (before >= Gs) continue;
                     const int cnt = (bin + 1 < BGB ? bins[bin + 1] : ns) - bins[bin];
-                    if (before + cnt <= Gs) grant(my);
+                    if (before + cnt <= Gs) grant(my, (e_ >> 20) & 63);
                     else { const int s_ = atomicAdd(&scal[B_NCROSS], 1); if (s_ < RCCAP) rcl[s_] = e_; }
                 }
                 __syncthreads();
                 const int ncross = scal[B_NCROSS];
                 if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; why = 4; time_exit = t; break; }
                 if (tid < ncross) {
-                    const int e_ = rcl[tid], my = e_ & 0xFFFFFF, sec = e_ >> 24;
+                    const int e_ = rcl[tid], my = e_ & 0xFFFFF, sec = e_ >> 26;
                     const int bin = sec * SB + (my >> shift);
                     int rank = bins[bin] - bins[sec * SB];
-                    for (int m = 0; m < ncross; m++) { const int o = rcl[m]; rank += ((o >> 24) == sec && ((o & 0xFFFFFF) >> shift) == (my >> shift) && (o & 0xFFFFFF) < my) ? 1 : 0; }
-                    if (rank < nGrantUL - 1 - scal[B_SGC + sec]) grant(my);
+                    for (int m = 0; m < ncross; m++) { const int o = rcl[m]; rank += ((o >> 26) == sec && ((o & 0xFFFFF) >> shift) == (my >> shift) && (o & 0xFFFFF) < my) ? 1 : 0; }
+                    if (rank < nGrantUL - 1 - scal[B_SGC + sec]) grant(my, (e_ >> 20) & 63);
                 }
                 __syncthreads(); // (the budgets were read above)
                 if (tid < 6) scal[B_SGC + tid] += bins[(tid + 1) * SB] - bins[tid * SB];
@@ -676,10 +668,11 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         } else if (Gr > 0 && ns > 0 && ns <= 64) {
             if (tid < 64) { // up to one wavefront of singleton callers: every lane ranks its own index against the others through v_readlane
                 const int nsu = __builtin_amdgcn_readfirstlane(ns);
-                const int my = tid < nsu ? BI(bl::SIDX)[tid] : INT_MAX;
+                const int sp = tid < nsu ? BI(bl::SIDX)[tid] : 0;
+                const int my = tid < nsu ? (sp & 0xFFFFF) : INT_MAX;
                 int rank = 0;
                 for (int s_ = 0; s_ < nsu; s_++) rank += __builtin_amdgcn_readlane(my, s_) < my ? 1 : 0;
-                if (tid < nsu && rank < Gr) grant(my);
+                if (tid < nsu && rank < Gr) grant(my, (sp >> 20) & 63);
             }
         } else if (Gr > 0 && ns > 0) {
             // the Gr lowest-index singleton callers, in O(ns): counts per index bin, block-wide exclusive prefix, whole bins below the
@@ -690,7 +683,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             for (int u_ = 0; u_ < PER; u_++) bins[tid * PER + u_] = 0;
             if (tid == 0) scal[B_NCROSS] = 0;
             __syncthreads();
-            for (int j = tid; j < ns; j += TB) atomicAdd(&bins[sidx[j] >> binshift], 1);
+            for (int j = tid; j < ns; j += TB) atomicAdd(&bins[(sidx[j] & 0xFFFFF) >> binshift], 1);
             __syncthreads();
             {
                 int c[PER], sum = 0;
@@ -706,31 +699,32 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             }
             __syncthreads();
             for (int j = tid; j < ns; j += TB) {
-                const int my = sidx[j];
+                const int sp = sidx[j], my = sp & 0xFFFFF;
                 const int bin = my >> binshift;
                 const int before = bins[bin];
                 if (before >= Gr) continue;
                 const int cnt = (bin + 1 < BGB ? bins[bin + 1] : ns) - before;
-                if (before + cnt <= Gr) grant(my);
-                else { const int s_ = atomicAdd(&scal[B_NCROSS], 1); if (s_ < RCCAP) rcl[s_] = my; }
+                if (before + cnt <= Gr) grant(my, (sp >> 20) & 63);
+                else { const int s_ = atomicAdd(&scal[B_NCROSS], 1); if (s_ < RCCAP) rcl[s_] = sp; }
             }
             __syncthreads();
             const int ncross = scal[B_NCROSS];
             if (ncross > RCCAP) { status = PRACH_ERR_INTERNAL; why = 4; time_exit = t; break; }
             if (tid < ncross) {
-                const int my = rcl[tid];
+                const int sp = rcl[tid], my = sp & 0xFFFFF;
                 int rank = bins[my >> binshift];
-                for (int m = 0; m < ncross; m++) rank += rcl[m] < my ? 1 : 0;
-                if (rank < Gr) grant(my);
+                for (int m = 0; m < ncross; m++) rank += (rcl[m] & 0xFFFFF) < my ? 1 : 0;
+                if (rank < Gr) grant(my, (sp >> 20) & 63);
             }
         }
         grantCheck += ns;
         BSTAMP(11); // grants
-        if ((Gr > 0 || sectors) && ns > 0) __syncthreads(); // S6: the grants are in the pass words before the next walk reads them
+        if ((Gr > 0 || sectors) && ns > 0) __syncthreads(); // S6: the grants are in the next subframe's event list and in the granted set before that subframe begins
         BSTAMP(12);
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }
     __syncthreads();
+    if (status == PRACH_OK && scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = 5; time_exit = tlast; } // (raised by the last subframe's grants)
 
     // ---- the state after the last subframe (deferred outcome + the subframes a UE was matched in since its record was written),
     // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508)
@@ -747,10 +741,10 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             UeState u = unpack(R.a);
             const ColdRegs cold = cold_unpack(R.b);
             if (status == PRACH_OK && tlast >= 0 && u.act != ACT_IDLE)
-                pw_catch_up(u, (unsigned)R.b.w, (int)__hip_atomic_load(pw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0, i, tend, K.fmA, tab);
+                pw_catch_up(u, (unsigned)R.b.w, granted_in(tlast & 1, i), i, tend, K.fmA, tab);
             const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
             if (u.act == ACT_DONE) { sumT += timer; ptcS += cold.ptc; fcS += cold.fcnt; }
-            ndS += (unsigned)R.b.x;
+            ndS += (unsigned)R.b.x & 0xFFFFFFu;
             timers[i] = u.act == ACT_DONE ? timer : INT_MIN;
             if (logs) {
                 prach_ue_log o;
@@ -781,12 +775,12 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         o->ptcSum = scal[B_PTC]; o->fcSum = scal[B_FC];
         o->nSuccess = scal[B_NSUCC]; o->finalSuccess = scal[B_NSUCC]; o->continueFailed = scal[B_CONTF];
         o->status = status;
-        o->hard_error = why; // (1 events, 2 reset-cycle candidates, 3 singleton callers, 4 crossing bin: reported by the engine)
+        o->hard_error = why; // (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 a calendar list or the granted list: reported by the engine)
         o->time_exit = time_exit;
         o->collisionPreambles = scal[B_COLL]; o->totalPreambleTxop = scal[B_TXOP];
         o->activeCheck = activeCheck;
         o->steps = steps;
-        o->visits = (unsigned long long)(unsigned)scal[B_VISITS];
+        o->visits = (unsigned long long)(unsigned)scal[B_JOINS]; // (join-calendar entries: one per contention window)
         o->events = (unsigned long long)(unsigned)scal[B_EVENTS];
 #ifdef PRACH_STAMPS
         for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];
@@ -798,7 +792,15 @@ size_t batch_kernel_lds_bytes(int waves, bool glibc) { return glibc ? (size_t)BL
 int batch_max_preambles() { return NPB; }
 int batch_max_rar_window() { return 64; }
 int batch_max_subframes() { return 65000; }
-int batch_max_groups(bool glibc) { return glibc ? BGG : BGROUPS; }
+int batch_max_groups(bool glibc) { return glibc ? BGG : (1 << 14); }
+int batch_max_rar_window_two_per_cu() { return BCap<8>::HRING; }
+int batch_calendar_slots(int backoff, int accessTime, int maxRarWindow) { // power of two >= the furthest a UE is ever scheduled ahead (+ its window), at most CR
+    const int need = backoff + (accessTime > 5 ? accessTime : 5) + maxRarWindow + 70;
+    int r = 64;
+    while (r < need) r *= 2;
+    return r;
+}
+int batch_max_calendar_slots() { return CR; }
 
 // waves: wavefronts per workgroup — 8: 512 threads, two workgroups (two independent trials) per CU; 16: 1024 threads, one per CU
 // glibc: the trials draw from the reference's own rand() stream (1024 threads only)

@@ -65,8 +65,12 @@ struct prach_engine {
     int64_t opt_noma_host_activation = 0; // 1: NOMA.c's activeUE table is built on the host (the reference's libm) instead of by noma_activation_kernel
     int64_t opt_noma_ambiguity_test = 0;  // test hook: the resolver reports every gain sort as ambiguous (exercises the rerun with the host-built table)
     bool force_host_act = false;   // (set for the rerun of trials whose device-built table left a gain comparison inside the error band)
+    int64_t opt_calendar_cap = 0;  // test hook: entries per calendar list of the batch kernel (0 = sized per trial)
+    bool full_calendars = false;   // (set for the rerun of batch-kernel trials that filled a calendar list: lists of nUE entries cannot fill)
+    std::vector<int> cal_overflow; // last launch: the trials that filled a calendar list
     int noma_flagged = 0, noma_ambiguous = 0; // last call: UEs recomputed on the host, trials rerun with the host-built table
     int num_cus = 256;
+    size_t mem_budget = (size_t)200 << 30; // arena bytes one launch may take (3/4 of the device's memory): a call that needs more runs as several launches
 };
 
 namespace {
@@ -76,7 +80,8 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, cand;
     size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0, sector;
-    size_t rec32, pw, qov, evov; // batch kernel
+    size_t rec32, ecal, jcal, qov, evov; // batch kernel
+    int calcap, calslots;
     size_t diag;                 // diagnostic build: per-workgroup stamps (zeroed region)
     size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
@@ -108,7 +113,7 @@ size_t mbox_bytes(const prach_cfg &c, int G, int &evw, int &mbstride) {
 }
 
 // stream_len[k]: glibc draw-stream window of trial k (0 in Philox mode); G: workgroups per trial (0 = trial_kernel)
-LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_ue_log *const *ue_logs, const std::vector<size_t> &stream_len, int G, bool batch) {
+LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_ue_log *const *ue_logs, const std::vector<size_t> &stream_len, int G, bool batch, bool full_calendars, int64_t calendar_cap) {
     LaunchLayout L;
     L.t.resize(m);
     size_t o = align_up(sizeof(TrialDev) * (size_t)m, 256);
@@ -144,9 +149,22 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         const prach_cfg &c = cfgs[idx[k]];
         TrialLayout &T = L.t[k];
         const size_t n = (size_t)c.nUE;
-        T.rec = T.ptc = T.ftt = T.stt = T.fcnt = T.nd = T.rec32 = T.pw = T.qov = T.evov = 0;
-        if (batch) { // prach_batch.hip: 32-byte event records, pass words padded to whole 64-UE groups, the queue's global part
-            T.rec32 = take(32 * n); T.pw = take(4 * ((n + 63) / 64 * 64 + 64)); T.qov = take(4 * n); T.evov = take(16 * n);
+        T.rec = T.ptc = T.ftt = T.stt = T.fcnt = T.nd = T.rec32 = T.ecal = T.jcal = T.qov = T.evov = 0;
+        T.calcap = T.calslots = 0;
+        if (batch) { // prach_batch.hip: 32-byte event records, the two calendars, the global parts of the candidate and event lists
+            // A calendar list holds the UEs scheduled into ONE subframe.  txTime is aligned to the access slots (Beta.c:268-277), so the UEs of a whole
+            // access slot open their windows — and, maxRarWindow - 1 subframes later, have their events — in the SAME subframe: an overloaded trial (more
+            // UEs than its UL grants can serve: every UE cycles through backoff and window about every 17 subframes) puts ~0.3 nUE into one list, a trial
+            // that is not overloaded far less.  A trial that fills a list anyway leaves with PRACH_ERR_INTERNAL and is rerun with lists of nUE entries,
+            // which cannot fill (run_trials_impl).  128 slots x 40 064 entries x 2 calendars = 41 MB for the overloaded 100 000-UE point, 13 MB otherwise.
+            T.calslots = batch_calendar_slots(c.backoff, c.accessTime, c.maxRarWindow);
+            const double steps_ = (double)((c.max_steps > 0 && c.max_steps < prach_max_time(&c)) ? c.max_steps : prach_max_time(&c));
+            const bool overloaded = (double)c.nUE > (double)std::max(0, c.nGrantUL - 1) * steps_ / 5.0;
+            T.calcap = (int)std::min(n, std::max<size_t>(4096, overloaded ? n * 2 / 5 : n / 8)) + 64;
+            if (calendar_cap > 0) T.calcap = (int)calendar_cap;
+            if (full_calendars) T.calcap = (int)n + 64;
+            T.rec32 = take(32 * n); T.ecal = take(4 * (size_t)T.calslots * (size_t)T.calcap); T.jcal = take(4 * (size_t)T.calslots * (size_t)T.calcap);
+            T.qov = take(4 * n); T.evov = take(16 * n);
         } else {
             T.rec = take(16 * n);
             T.ptc = take(4 * n); T.ftt = take(4 * n); T.stt = take(4 * n); T.fcnt = take(4 * n); T.nd = take(4 * n);
@@ -285,6 +303,7 @@ static int engine_create_impl(int device, prach_engine **out) {
     if (!e) return PRACH_ERR_DEVICE;
     e->device = device;
     e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e->mem_budget = (size_t)prop.totalGlobalMem / 4 * 3;
     int rc = [&]() -> int {
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&e->ev0));
@@ -323,7 +342,7 @@ static bool use_fast_kernel(const prach_engine *e, int lslots, int maxP) {
 static bool batch_eligible(const prach_engine *e, const prach_cfg &c) {
     if (c.variant == PRACH_VARIANT_NOMA_C || !e->opt_batch || e->opt_dense || e->opt_wide_records) return false;
     const bool glibc = c.rng_mode == PRACH_RNG_GLIBC;
-    return c.nPreamble <= batch_max_preambles() && c.maxRarWindow <= batch_max_rar_window() &&
+    return c.nPreamble <= batch_max_preambles() && c.maxRarWindow <= batch_max_rar_window() && batch_calendar_slots(c.backoff, c.accessTime, c.maxRarWindow) <= batch_max_calendar_slots() &&
            (int64_t)prach_max_time(&c) + c.backoff + c.accessTime + 128 < batch_max_subframes() && c.nUE < (1 << 20) - 1 && (c.nUE + 63) / 64 <= batch_max_groups(glibc);
 }
 
@@ -384,7 +403,13 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if ((cfgs[idx[k]].flags & PRACH_FLAG_SECTOR_GRANTS) && G > 0 && !batch) return PRACH_ERR_INTERNAL;
     // NOMA.c's activeUE table: built by the device (noma_activation_kernel) unless the option or a rerun asks for the host's libm
     const bool host_act = noma && (e->opt_noma_host_activation || e->force_host_act);
-    const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G, batch);
+    const LaunchLayout LL = layout_launch(cfgs, idx, m, ue_logs, slen, G, batch, e->full_calendars, e->opt_calendar_cap);
+    if (LL.end > e->mem_budget && m > 1) { // (e.g. the 10 000-trial grid with its calendars on ONE GPU: two or three launches instead of one)
+        const int h = m / 2;
+        int rc = run_group(e, cfgs, idx, h, results, ue_logs, attempt, G, kernel_ms, upload_ms);
+        if (rc != PRACH_OK) return rc;
+        return run_group(e, cfgs, idx + h, m - h, results, ue_logs, attempt, G, kernel_ms, upload_ms);
+    }
     { int rc = ensure_arena(e, LL.end); if (rc != PRACH_OK) return rc; }
     { int rc = ensure_pinned(e, std::max(LL.staged_end, sizeof(DevResult) * (size_t)m)); if (rc != PRACH_OK) return rc; }
     auto t0 = std::chrono::steady_clock::now();
@@ -406,7 +431,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.dense_pass = e->opt_dense ? 1 : 0;
         d.pipeline = e->opt_pipeline ? 1 : 0;
         if (batch) {
-            d.rec32 = reinterpret_cast<int4 *>(A + L.rec32); d.pw = reinterpret_cast<unsigned *>(A + L.pw); d.qov = reinterpret_cast<int *>(A + L.qov); d.evov = reinterpret_cast<int2 *>(A + L.evov);
+            d.rec32 = reinterpret_cast<int4 *>(A + L.rec32); d.ecal = reinterpret_cast<int *>(A + L.ecal); d.jcal = reinterpret_cast<int *>(A + L.jcal); d.calcap = L.calcap; d.calmask = L.calslots - 1;
+            d.qov = reinterpret_cast<int *>(A + L.qov); d.evov = reinterpret_cast<int2 *>(A + L.evov);
         } else {
             d.rec = reinterpret_cast<int4 *>(A + L.rec);
             d.ptc = reinterpret_cast<int *>(A + L.ptc); d.ftt = reinterpret_cast<int *>(A + L.ftt);
@@ -553,6 +579,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             }
             waves = (m >= 3 * e->num_cus && upd_over < 0.5 * upd_all) ? 8 : 16;
         }
+        for (int k = 0; k < m; k++) // (the 512-thread shape keeps a 16-subframe histogram ring)
+            if (cfgs[idx[k]].maxRarWindow > batch_max_rar_window_two_per_cu()) waves = 16;
         e->last.workgroups = m;
         HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, waves, rng_mode == PRACH_RNG_GLIBC, e->stream));
     }
@@ -628,7 +656,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (std::getenv("PRACH_PRINT_STAMPS")) {
             static const char *const nm[24] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "window-rest", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "phaseA",
                                                "w:phaseA|A-barrier", "w:loads", "w:refill", "t:buckets", "-", "-", "-", "-"};
-            static const char *const nmb[24] = {"head", "walk", "walk-barrier", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "-", "-", "-",
+            static const char *const nmb[24] = {"head", "joins", "-", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "-", "-", "-",
                                                 "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_batch.hip
             static const char *const nmn[24] = {"head", "publish+gather", "gather-barrier", "resolve(w0)", "resolve-barrier", "passB+A(w0)", "pass-barrier", "-", "r:to-gains", "r:rank+sort", "r:pairing", "-", "-", "-", "-", "-",
                                                 "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_noma.hip, per SUBFRAME (x accessTime = per slot)
@@ -652,8 +680,9 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         }
         if (dr.status != PRACH_OK && e->last.rec_mode == CLUSTER_REC_LFAST && std::getenv("PRACH_VERBOSE"))
             std::fprintf(stderr, "[prach] lcluster_kernel: trial nUE=%d left at subframe %d with status %d, capacity code %d\n", c.nUE, dr.time_exit, dr.status, dr.hard_error);
+        if (batch && dr.status == PRACH_ERR_INTERNAL && dr.hard_error == 5 && !e->full_calendars) e->cal_overflow.push_back(idx[k]);
         if (dr.status == PRACH_ERR_INTERNAL && e->last.rec_mode == CLUSTER_REC_BATCH && std::getenv("PRACH_VERBOSE"))
-            std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d left at subframe %d: capacity %d (1 events, 2 reset-cycle candidates, 3 singleton callers, 4 crossing bin)\n", c.nUE, dr.time_exit, dr.hard_error);
+            std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d left at subframe %d: capacity %d (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 a calendar list / the granted list)\n", c.nUE, dr.time_exit, dr.hard_error);
         if (dr.status != PRACH_OK) continue;
         // totalDelay is a FLOAT running sum in index order (Beta.c:186,193): exact in integer
         // arithmetic while it stays below 2^24, otherwise replay the float additions on the host.
@@ -681,6 +710,28 @@ static void note_fallback(prach_engine *e, const char *what, size_t ntrials, siz
     e->last.spin_timeouts += (int32_t)ntimeouts;
     std::fprintf(stderr, "[prach] %zu trial(s) of a %d-workgroup cluster launch are rerun on %s (%zu exceeded a per-subframe capacity, %zu timed out "
                          "waiting for a peer workgroup: cluster not co-resident?)\n", ntrials, G, what, ntrials - ntimeouts, ntimeouts);
+}
+
+// Batch-kernel trials that filled a calendar list (a parameter set that synchronises more UEs onto one subframe than the list was sized for): once more on the
+// same kernel with lists of nUE entries, which cannot fill.  Never silently: counted as fallback trials and reported.
+static int rerun_full_calendars(prach_engine *e, const prach_cfg *cfgs, prach_result *results, prach_ue_log *const *ue_logs, double &kernel_ms, double &upload_ms) {
+    if (e->cal_overflow.empty()) return PRACH_OK;
+    std::vector<int> todo;
+    todo.swap(e->cal_overflow);
+    e->last.fallback_trials += (int32_t)todo.size();
+    std::fprintf(stderr, "[prach] %zu trial(s) filled a calendar list of prach::batch_kernel: rerun with lists of nUE entries\n", todo.size());
+    e->full_calendars = true;
+    int rc = PRACH_OK;
+    for (int attempt = 0; !todo.empty() && rc == PRACH_OK; attempt++) {
+        if (attempt > 6) { rc = PRACH_ERR_STREAM; break; }
+        rc = run_group(e, cfgs, todo.data(), (int)todo.size(), results, ue_logs, attempt, 1, kernel_ms, upload_ms);
+        std::vector<int> again;
+        for (int k : todo) if (results[k].status == PRACH_ERR_STREAM) again.push_back(k); // (the reference's stream: a larger window)
+        todo.swap(again);
+    }
+    e->full_calendars = false;
+    e->cal_overflow.clear();
+    return rc;
 }
 
 static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_result *results, prach_ue_log *const *ue_logs) {
@@ -818,6 +869,8 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
                 // what exceeds a capacity of its resolver goes on to trial_kernel like any other trial)
                 int rc = run_group(e, cfgs, sect.data(), (int)sect.size(), results, ue_logs, 0, 1, kernel_ms, upload_ms);
                 if (rc != PRACH_OK) return rc;
+                rc = rerun_full_calendars(e, cfgs, results, ue_logs, kernel_ms, upload_ms);
+                if (rc != PRACH_OK) return rc;
                 size_t nbad = 0;
                 for (int k : sect) if (results[k].status != PRACH_OK) { solo.push_back(k); nbad++; }
                 if (nbad) { note_fallback(e, "trial_kernel (one workgroup per trial, no per-subframe capacity)", nbad, 0, 1); e->last.trial_kernel_reruns += (int32_t)nbad; }
@@ -868,6 +921,8 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
                 if (attempt > 6) return PRACH_ERR_STREAM;
                 int rc = run_group(e, cfgs, todo.data(), (int)todo.size(), results, ue_logs, attempt, G, kernel_ms, upload_ms);
                 if (rc != PRACH_OK) return rc;
+                rc = rerun_full_calendars(e, cfgs, results, ue_logs, kernel_ms, upload_ms); // (one workgroup per trial on the batch kernel: a full calendar list)
+                if (rc != PRACH_OK) return rc;
                 std::vector<int> again;
                 const bool was_packed = e->last.xcd_packed != 0;
                 e->pack_off = false;
@@ -900,6 +955,8 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
                 // continues in global memory) and still runs all 16 wavefronts on the trial, so such trials go there first — the
                 // one-workgroup, index-ordered trial_kernel (no per-subframe capacity at all, ~10x slower) only gets what is left.
                 int rc = run_group(e, cfgs, idx.data(), (int)idx.size(), results, ue_logs, 0, 1, kernel_ms, upload_ms);
+                if (rc != PRACH_OK) return rc;
+                rc = rerun_full_calendars(e, cfgs, results, ue_logs, kernel_ms, upload_ms);
                 if (rc != PRACH_OK) return rc;
                 std::vector<int> still;
                 for (int k : idx) if (results[k].status != PRACH_OK) still.push_back(k);
@@ -980,6 +1037,8 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "plain_arena") == 0) { if (e->arena_cap) return PRACH_ERR_ARG; e->opt_plain_arena = value != 0; return PRACH_OK; } // (before the first call only)
     if (std::strcmp(key, "noma_ambiguity_test") == 0) { e->opt_noma_ambiguity_test = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "noma_host_activation") == 0) { e->opt_noma_host_activation = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "mem_budget_mb") == 0) { if (value <= 0) return PRACH_ERR_ARG; e->mem_budget = (size_t)value << 20; return PRACH_OK; } // (test hook: split launches)
+    if (std::strcmp(key, "calendar_cap") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_calendar_cap = value; return PRACH_OK; }
     if (std::strcmp(key, "batch_waves") == 0) { if (value != 0 && value != 8 && value != 16) return PRACH_ERR_ARG; e->opt_batch_waves = value; return PRACH_OK; }
     if (std::strcmp(key, "xcd_pack") == 0) { e->opt_xcd_pack = value != 0; return PRACH_OK; }
     return PRACH_ERR_ARG;
