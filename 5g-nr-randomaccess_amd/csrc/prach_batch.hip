@@ -45,6 +45,24 @@ namespace {
 #define BSTAMP(k) do { } while (0)
 #endif
 
+#ifndef PRACH_B_K1
+#define PRACH_B_K1 1   // (experiment switch) 0: no separate list / short path for "window closes, retransmit" events
+#endif
+#ifndef PRACH_B_W8_WAVES
+#define PRACH_B_W8_WAVES 6 // (experiment switch) wavefronts per SIMD the 512-thread shape is compiled for: 4 = two workgroups per CU, 6 = three
+#endif
+#ifndef PRACH_B_XVALU
+#define PRACH_B_XVALU 0 // (sensitivity experiment) extra Philox draws per event batch, results unused
+#endif
+#ifndef PRACH_B_XLDS
+#define PRACH_B_XLDS 0  // (sensitivity experiment) extra returning LDS atomics per event batch (on a dummy word)
+#endif
+#ifndef PRACH_B_XST
+#define PRACH_B_XST 0   // (sensitivity experiment) extra scattered 4-byte global stores per event batch (into the UE's own record word 7, rewritten right after)
+#endif
+#ifndef PRACH_B_PIPE
+#define PRACH_B_PIPE 1 // (experiment switch) 0: the compiler places the waits for the next batch's loads
+#endif
 constexpr int NPB = 64;       // stride of the per-bucket tables (nPreamble <= 64)
 constexpr int BSC = 2048;     // singleton callers per subframe
 constexpr int BGB = 1024;     // grant selection bins
@@ -54,11 +72,11 @@ constexpr int CR = 256;       // calendar slots: the fill counts of the subframe
 // records, the other one issues).  What is held in LDS per subframe (event list and candidate list continue in global memory; the singleton
 // list BSC, the reset-cycle / crossing-bin lists RCCAP and the granted list are capacities: beyond them the engine reruns the trial on trial_kernel):
 template <int NWB> struct BCap {
-    static constexpr int EV = NWB == 16 ? 4096 : 2048;    // events of a subframe held in LDS (more: global memory)
+    static constexpr int EV = NWB == 16 ? 4096 : 1536;    // events of a subframe held in LDS (more: global memory)
 #ifdef PRACH_QCAP
     static constexpr int CAND = PRACH_QCAP;                 // (test build: nearly every subframe's candidate list continues in global memory)
 #else
-    static constexpr int CAND = NWB == 16 ? 4096 : 2048;  // early-leaver candidates of a subframe held in LDS (more: global memory)
+    static constexpr int CAND = NWB == 16 ? 4096 : 1024;  // early-leaver candidates of a subframe held in LDS (more: global memory)
 #endif
     static constexpr int HRING = NWB == 16 ? 64 : 16;     // subframes ahead the histogram / lowest-index ring holds: a window lasts maxRarWindow - 1 < HRING subframes
     static constexpr int GBITS = NWB == 16 ? 32768 : 16384; // granted-UE bitmap (bit = UE index mod GBITS: exact below that many UEs, else a filter in front of the list)
@@ -88,15 +106,16 @@ template <int NWB> struct BL {
     static constexpr int FMINP = FIE + 4 * NPB;            // int [NPB] the lowest matched UE of every bucket as the ring held it: index << 6 | subframes of its window still ahead
     static constexpr int HR = FMINP + 4 * NPB;             // int [HRING][NPB] histogram ring: matched UEs per bucket in the subframes t .. t + HRING - 1 (slot = subframe mod HRING)
     static constexpr int MR = HR + 4 * C::HRING * NPB;     // int [HRING][NPB] lowest matched index << 6 | remaining window, same ring
-    static constexpr int ECNT = MR + 4 * C::HRING * NPB;   // int [CR] entries in the event calendar's list of the subframes t .. (slot = subframe & calmask)
-    static constexpr int JCNT = ECNT + 4 * CR;             // int [CR] ... in the join calendar's
+    static constexpr int ECNT = MR + 4 * C::HRING * NPB;   // int [2][CR] entries in the event calendar's list of the subframes t .. (slot = subframe & calmask): [0] "window closes,
+                                                           // retransmit" events, filled from the list's front; [1] every other event, filled from its back
+    static constexpr int JCNT = ECNT + 8 * CR;             // int [CR] ... in the join calendar's
     static constexpr int GBM = JCNT + 4 * CR;              // unsigned [2][GBITS / 32] granted-UE bitmap, by subframe parity
     static constexpr int GLIST = GBM + 2 * C::GBITS / 8;   // int [2][GL] granted UEs, by subframe parity
     static constexpr int CANDL = GLIST + 2 * 4 * C::GL;    // int [CAND] early-leaver candidates: index | old bucket << 20
     static constexpr int END = CANDL + 4 * C::CAND;
     static_assert(SIDX % 16 == 0 && HR % 16 == 0, "alignment");
 };
-static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
+static_assert(BL<8>::END <= 160 * 1024 / 3, "three 512-thread workgroups per CU");
 // The reference's own rand() stream (GLIBC instantiation, 1024 threads): per 64-UE group of the trial, the lanes that make at least one / two rand()
 // calls in this subframe (two 64-bit masks) and the group's exclusive prefix of calls in index order.  BGG groups = 131 072 UEs at most.
 constexpr int BGG = 2048;
@@ -141,7 +160,7 @@ constexpr int CAL_GRANT = (int)0x80000000u;
 // many calls each event UE makes follows from its pre-step state) that marks the calling lanes of every group, a block-wide prefix over
 // the groups in index order, then the full body as the SELECT pass with d1, d2 = stream[base + prefix[group] + calls of the group's lower lanes].
 template <int NWB, bool GLIBC = false>
-__global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restrict__ params) {
+__global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void batch_kernel(const TrialDev *__restrict__ params) {
     static_assert(!GLIBC || NWB == 16, "the reference-stream form exists in the 1024-thread shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using bl = BL<NWB>;
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
     // calloc + initialUE (Beta.c:78-83)
     for (int i = tid; i < nUE; i += TB) brec_store(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0), make_int4(0, 0, 0, (int)PW_IDLE));
     for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; }
-    for (int k = tid; k < CR; k += TB) { ecnt[k] = 0; jcnt[k] = 0; }
+    for (int k = tid; k < CR; k += TB) { ecnt[k] = 0; ecnt[CR + k] = 0; jcnt[k] = 0; }
     for (int k = tid; k < 2 * GBITS / 32; k += TB) BU(bl::GBM)[k] = 0u;
     if (tid < NPB) {
         BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; BI(bl::FMINP)[tid] = INT_MAX;
@@ -231,8 +250,10 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
         int *const fcallB = BI(bl::FCALL) + (parity ^ 1) * NPB, *const lcallB = BI(bl::LCALL) + (parity ^ 1) * NPB;
         const int slot = (int)((unsigned)t & calmask);                       // this subframe's calendar lists
         int *const histx = hr + (t & (HRING - 1)) * NPB, *const mlocx = mr + (t & (HRING - 1)) * NPB; // ... and its histogram / lowest matched index << 6 | window left
-        const int ne = ecnt[slot], nj = jcnt[slot];                           // complete: every entry was made in an earlier subframe (the grants' behind S6)
+        const int n1 = ecnt[slot], ne = ecnt[CR + slot], nj = jcnt[slot];     // complete: every entry was made in an earlier subframe (the grants' behind S6)
         const int qn = ne + (activeCheck - prevAC);                           // this access slot's arrivals (Beta.c:136-146) are events too: virtual entries behind the list's
+        PRACH_G int *const elist = ecal + (size_t)slot * (size_t)calcap;      // retransmission events [0, n1) from the front, the other ne from the back
+        if (n1 + ne > calcap) scal[B_OVF] = 1;                                // (the two ends have met: the trial leaves behind S2 and is rerun with longer lists)
         BSTAMP(0); // loop head
 
         // ================= joins: UEs whose contention window opens in this subframe enter the ring's subframes t .. t + dur - 1 =================
@@ -260,33 +281,113 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             int c_succ = 0, c_contf = 0;
             const int tmod = t % aT;
             const CallTables tab{fcallB, lcallB};
-            struct Batch { int e; bool v; BRec R; };
-            auto fetch_batch = [&](const int q0) -> Batch { // (record 0 is always mapped: an idle lane loads it and ignores it)
-                Batch B;
-                const int q = q0 + lane;
-                B.v = q < qn;
-                B.e = 0;
-                if (B.v) B.e = q < ne ? ecal[(size_t)slot * (size_t)calcap + (size_t)q] : prevAC + (q - ne);
-                B.R = brec_load(rec32 + 2 * (size_t)(B.e & 0xFFFFF));
-                return B;
+            // The loop over a list's batches is written for gfx950's ONE in-order memory counter (loads and stores complete in issue order as far as
+            // s_waitcnt vmcnt can tell): at the top of a batch the records of the NEXT batch and the list entries of the one after are requested; they are
+            // waited for once, right before this batch's stores are issued (pipe_sync: by then they have had the whole batch to arrive), and the stores then
+            // have the next batch's compute phase to complete before anything waits again.  (Waiting at the top of the next batch instead — where the
+            // compiler puts it — waits for the scattered stores as well: measured, that was most of the event body's time under load.)
+            int pe_n2 = 0;      // list entry of this lane two batches ahead
+            BRec pR_n;          // record of this lane's UE in the next batch
+            pR_n.a = pR_n.b = make_int4(0, 0, 0, 0);
+            auto pipe_sync = [&]() __attribute__((always_inline)) {
+                if (PRACH_B_PIPE) asm volatile("" :: "v"(pR_n.a.x), "v"(pR_n.a.y), "v"(pR_n.a.z), "v"(pR_n.a.w), "v"(pR_n.b.x), "v"(pR_n.b.y), "v"(pR_n.b.z), "v"(pR_n.b.w), "v"(pe_n2));
+            };
+            auto entry_other = [&](const int q) -> int { return q < qn ? (q < ne ? elist[calcap - 1 - q] : prevAC + (q - ne)) : 0; }; // (arrivals: virtual entries)
+            auto entry_retx = [&](const int q) -> int { return q < n1 ? elist[q] : 0; };
+            auto rec_of = [&](const int e) -> BRec { return brec_load(rec32 + 2 * (size_t)(e & 0xFFFFF)); }; // (record 0 is always mapped: an idle lane loads it and ignores it)
+            // what follows selectPreamble / requestResourceAllocation for every event UE: bucket bookkeeping, special events for the resolver, the UE's schedule
+            auto finish = [&](const bool v, const int i, UeState &u, ColdRegs &cold, const unsigned nd, const unsigned gen, const UeOut &o) __attribute__((always_inline)) {
+                BSTAMP(13); // (fine stamps of the diagnostic build: select logic)
+                if (PRACH_B_XVALU) { // (sensitivity experiment: never changes a result)
+                    int x_ = 0;
+#pragma unroll
+                    for (int k_ = 0; k_ < PRACH_B_XVALU; k_++) x_ ^= philox_draw31(seed_lo, seed_hi, (unsigned)i, nd + 77u + (unsigned)k_, (unsigned)nUE, (unsigned)variant);
+                    if (x_ == 0x7fffffff && nd == 0xfffffffu) scal[B_OVF] = 3;
+                }
+                if (PRACH_B_XLDS) {
+                    int y_ = 0;
+#pragma unroll
+                    for (int k_ = 0; k_ < PRACH_B_XLDS; k_++) y_ += atomicAdd(&scal[40 + (k_ & 7)], 1);
+                    if (y_ == 0x7fffffff) scal[B_OVF] = 3;
+                }
+                if (PRACH_B_XST) {
+#pragma unroll
+                    for (int k_ = 0; k_ < PRACH_B_XST; k_++) if (v) reinterpret_cast<PRACH_G int *>(rec32)[8 * (size_t)i + 7] = k_;
+                }
+                // ---- bucket bookkeeping (this subframe's ring slot; an event UE has nothing in the later ones: window left = 0) ----
+                if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
+                if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i << 6);
+                if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i << 6);
+                {
+                    const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(o.eclass);
+                    if (em | cm) {
+                        int b_ev = 0, b_cd = 0;
+                        if (lane == 0) {
+                            if (em) b_ev = atomicAdd(&scal[B_NEV + parity], __popcll(em));
+                            if (cm) b_cd = atomicAdd(&scal[B_NCAND + parity], __popcll(cm));
+                        }
+                        b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
+                        if (o.evtype != UEV_NONE) {
+                            const int es = b_ev + __popcll(em & lanemask_lt(lane));
+                            ev_set(es, i, ue_event_info(o));
+                        }
+                        if (o.eclass) {
+                            const int cs = b_cd + __popcll(cm & lanemask_lt(lane)), cv = i | (o.oldp << 20);
+                            if (cs < CCAP) candl[cs] = cv; else candg[cs - CCAP] = cv;
+                        }
+                    }
+                }
+                BSTAMP(14); // bucket bookkeeping, special events
+                // the UE's schedule from here (prach_ue_body.h): matched in [tj, tj + dur), its next event at tj + dur — into the calendars
+                bool k1 = false;
+                unsigned word = PW_IDLE;
+                if (v) word = pw_schedule(u, t, K.maxRar, K.maxMsg2, k1);
+                if (GLIBC || !PRACH_B_K1) k1 = false; // (the reference-stream form runs every event through the count / select passes)
+                const unsigned gen1 = (gen + 1u) & 0xFFu;
+                const unsigned tjn = word & 0xFFFFu, durn = (word >> 16) & 0x3Fu;
+                const bool sched_ = v && tjn != 0xFFFFu; // (0xFFFF: finished for good, or a txTime that never comes — Beta.c:167)
+                // list positions: one returning LDS atomic per lane and list, both issued before either is waited for (the UEs of a batch go to a handful of
+                // subframes — txTime is aligned to the access slots — so the lanes meet on a few words: ~64 LDS cycles each, but ONE round trip; a wavefront-
+                // aggregated form, one atomic per distinct subframe, measured slower: five dependent round trips)
+                const int js = (int)(tjn & calmask), es_ = (int)((tjn + durn) & calmask);
+                int jp = 0, ep = 0;
+                if (sched_ && durn > 0u) jp = atomicAdd(&jcnt[js], 1);
+                if (sched_) ep = atomicAdd(&ecnt[k1 ? es_ : CR + es_], 1);
+                BSTAMP(15); // schedule, list positions
+                pipe_sync(); // the next batch's records and the entries behind them have arrived: from here on only stores are issued
+                BSTAMP(16); // wait for the next batch
+                if (v) brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, gen1, cold, word));
+                if (sched_) {
+                    if (durn > 0u) {
+                        if (jp < calcap) jcal[(size_t)js * (size_t)calcap + (size_t)jp] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
+                        else scal[B_OVF] = 1;
+                    }
+                    if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)(k1 ? ep : calcap - 1 - ep)] = (int)((unsigned)i | (gen1 << 20));
+                    else scal[B_OVF] = 1;
+                }
+                BSTAMP(17); // stores
             };
             // MODE 0: Philox, everything in one pass.  MODE 1 (GLIBC): the count pass — nothing is stored but the calling lanes.  MODE 2 (GLIBC): the full
             // body with the draws at their stream positions (sbase: position of the subframe's first call of the UE loop).
             auto body_pass = [&](auto MODE_, const unsigned long long sbase) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(MODE_)::value;
-                Batch Bn = fetch_batch(w * 64);
-                for (int q0 = w * 64; q0 < qn; q0 += NWB * 64) {
-                    const Batch Bc = Bn;
-                    if (q0 + NWB * 64 < qn) Bn = fetch_batch(q0 + NWB * 64); // in flight while this batch is worked on
-                    const int e = Bc.e;
+                constexpr int ST = NWB * 64;
+                int e_c = entry_other(w * 64 + lane), e_n = entry_other(w * 64 + ST + lane);
+                BRec R_c = rec_of(e_c);
+                asm volatile("" :: "v"(R_c.a.x), "v"(R_c.a.y), "v"(R_c.a.z), "v"(R_c.a.w), "v"(R_c.b.x), "v"(R_c.b.y), "v"(R_c.b.z), "v"(R_c.b.w), "v"(e_n)); // (the first batch is waited for HERE, not at every batch's top)
+                for (int q0 = w * 64; q0 < qn; q0 += ST) {
+                    if (q0 + ST < qn) { pR_n = rec_of(e_n); pe_n2 = entry_other(q0 + 2 * ST + lane); } // in flight while this batch is worked on
+                    const int e = e_c;
                     const int i = e & 0xFFFFF;
                     const bool granted = e < 0;
                     const bool arrival = q0 + lane >= ne;
-                    BRec R = Bc.R;
+                    BRec R = R_c;
+                    // (the next batch moves into place at the END of this one, behind pipe_sync: a register move of a value still in flight would wait for it here)
+                    auto rotate = [&]() __attribute__((always_inline)) { e_c = e_n; e_n = pe_n2; R_c = pR_n; };
                     const unsigned gen = (unsigned)R.b.x >> 24;
                     // An entry counts if it is the UE's current one: a grant entry always; any other one not when the UE was granted in the subframe before (its
                     // grant entry does the work) and not when the UE has been rescheduled since the entry was made (a grant took it out of its window early)
-                    bool v = Bc.v;
+                    bool v = q0 + lane < qn;
                     if (v && !granted && !arrival) v = (unsigned)((e >> 20) & 0xFF) == gen && !granted_in(parity ^ 1, i);
                     if (!v) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
                     UeState u = unpack(R.a);
@@ -307,6 +408,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                             atomicOr(&gm[4 * g_ + (ln >> 5)], 1u << (ln & 31));
                             if (pl.need == 2) atomicOr(&gm[4 * g_ + 2 + (ln >> 5)], 1u << (ln & 31));
                         }
+                        rotate();
                         continue;
                     }
                     int d1 = 0, d2 = 0;
@@ -324,48 +426,38 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                         nd += (unsigned)pl.need;
                     }
                     const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
-                    // ---- bucket bookkeeping (this subframe's ring slot; an event UE has nothing in the later ones: window left = 0) ----
-                    if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
-                    if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i << 6);
-                    if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i << 6);
-                    {
-                        const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(o.eclass);
-                        if (em | cm) {
-                            int b_ev = 0, b_cd = 0;
-                            if (lane == 0) {
-                                if (em) b_ev = atomicAdd(&scal[B_NEV + parity], __popcll(em));
-                                if (cm) b_cd = atomicAdd(&scal[B_NCAND + parity], __popcll(cm));
-                            }
-                            b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
-                            if (o.evtype != UEV_NONE) {
-                                const int es = b_ev + __popcll(em & lanemask_lt(lane));
-                                ev_set(es, i, ue_event_info(o));
-                            }
-                            if (o.eclass) {
-                                const int cs = b_cd + __popcll(cm & lanemask_lt(lane)), cv = i | (o.oldp << 20);
-                                if (cs < CCAP) candl[cs] = cv; else candg[cs - CCAP] = cv;
-                            }
-                        }
-                    }
-                    if (v) {
-                        // the UE's schedule from here (prach_ue_body.h): matched in [tj, tj + dur), its next event at tj + dur — into the calendars
-                        const unsigned word = pw_schedule<false>(u, t, K.maxRar);
-                        const unsigned gen1 = (gen + 1u) & 0xFFu;
-                        brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, gen1, cold, word));
-                        const unsigned tjn = word & 0xFFFFu, durn = (word >> 16) & 0x3Fu;
-                        if (tjn != 0xFFFFu) { // (0xFFFF: finished for good, or a txTime that never comes — Beta.c:167)
-                            if (durn > 0u) {
-                                const int js = (int)(tjn & calmask), jp = atomicAdd(&jcnt[js], 1);
-                                if (jp < calcap) jcal[(size_t)js * (size_t)calcap + (size_t)jp] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
-                                else scal[B_OVF] = 1;
-                            }
-                            const int es_ = (int)((tjn + durn) & calmask), ep = atomicAdd(&ecnt[es_], 1);
-                            if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)ep] = (int)((unsigned)i | (gen1 << 20));
-                            else scal[B_OVF] = 1;
-                        }
-                    }
+                    finish(v, i, u, cold, nd, gen, o);
+                    rotate();
                 }
             };
+            // "the RAR window closes, retransmit" (prach_ue_body.h ue_window_retx): the events listed at the front of the subframe's list, one short path for all 64 lanes
+            if (!GLIBC) {
+                constexpr int ST = NWB * 64;
+                const int qs = (NWB - 1 - w) * 64; // (from the last wavefront down: the first ones have the most batches of the other list)
+                int e_c = entry_retx(qs + lane), e_n = entry_retx(qs + ST + lane);
+                BRec R_c = rec_of(e_c);
+                asm volatile("" :: "v"(R_c.a.x), "v"(R_c.a.y), "v"(R_c.a.z), "v"(R_c.a.w), "v"(R_c.b.x), "v"(R_c.b.y), "v"(R_c.b.z), "v"(R_c.b.w), "v"(e_n));
+                for (int q0 = qs; q0 < n1; q0 += ST) {
+                    if (q0 + ST < n1) { pR_n = rec_of(e_n); pe_n2 = entry_retx(q0 + 2 * ST + lane); }
+                    const int e = e_c;
+                    const int i = e & 0xFFFFF;
+                    BRec R = R_c;
+                    const unsigned gen = (unsigned)R.b.x >> 24;
+                    const bool v = q0 + lane < n1 && (unsigned)((e >> 20) & 0xFF) == gen && !granted_in(parity ^ 1, i); // (as in body_pass)
+                    if (!v) { R.a = make_int4(0, 0, 0, ACT_M1 | (1 << PK_PRE_SHIFT)); R.b = make_int4(0, 0, 0, (int)pw_make(t, 0, 0)); }
+                    UeState u = unpack(R.a);
+                    ColdRegs cold = cold_unpack(R.b);
+                    unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
+                    const int d1 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd, (unsigned)nUE, (unsigned)variant);
+                    nd += 1u;
+                    bool ok;
+                    UeOut o = ue_window_retx(u, (unsigned)R.b.w, d1, i, t, K, cold, ok);
+                    if (v && !ok) scal[B_OVF] = 2; // (a record that is not in the state its list promises: reported, the trial is rerun on trial_kernel)
+                    if (!v) { o.evtype = UEV_NONE; o.member_pre = false; o.eclass = false; u.pend = PEND_NONE; }
+                    finish(v, i, u, cold, nd, gen, o);
+                    e_c = e_n; e_n = pe_n2; R_c = pR_n; // (behind pipe_sync: the next batch moves into place)
+                }
+            }
             if (!GLIBC) body_pass(std::integral_constant<int, 0>{}, 0ull);
             else {
                 // activateUEs' two rand() calls per arrival (WithNOMA:393-394) come first in the subframe, in index order; nothing reads them here
@@ -425,7 +517,7 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             }
             if (GLIBC) // every draw of this subframe has been read: the marks of the groups the event UEs are in can go
                 for (int q = tid; q < qn; q += TB) {
-                    const int i = q < ne ? (ecal[(size_t)slot * (size_t)calcap + (size_t)q] & 0xFFFFF) : prevAC + (q - ne);
+                    const int i = q < ne ? (elist[calcap - 1 - q] & 0xFFFFF) : prevAC + (q - ne);
                     *reinterpret_cast<uint4 *>(&gm[4 * (i >> 6)]) = make_uint4(0u, 0u, 0u, 0u);
                 }
             { // the granted set of subframe t - 1 has been used by every join and every event of this subframe: empty it (bit by bit, from its list)
@@ -441,15 +533,15 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
                 BI(bl::TOTAL)[tid] = histx[tid]; fcallA[tid] = m_ == INT_MAX ? INT_MAX : (m_ >> 6); BI(bl::FMINP)[tid] = m_;
             }
             if (tid == 0) {
-                scal[B_EVENTS] += qn; scal[B_JOINS] += nj; // (reported, never read by the simulation)
+                scal[B_EVENTS] += qn + n1; scal[B_JOINS] += nj; // (reported, never read by the simulation)
                 scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0;
-                ecnt[slot] = 0; jcnt[slot] = 0; // (this slot is the subframe t + calmask + 1 from here on: nothing is scheduled that far ahead)
+                ecnt[slot] = 0; ecnt[CR + slot] = 0; jcnt[slot] = 0; // (this slot is the subframe t + calmask + 1 from here on: nothing is scheduled that far ahead)
             }
         }
         BSTAMP(5); // leaver filter
         __syncthreads(); // S2
         BSTAMP(6);
-        if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = 5; time_exit = t; break; } // a calendar list (or the granted list, a subframe ago) was full
+        if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = scal[B_OVF] == 2 ? 6 : 5; time_exit = t; break; } // a calendar list (or the granted list, a subframe ago) was full
         const int N = scal[B_NEV + parity];
         if (tid < NPB) { histx[tid] = 0; mlocx[tid] = INT_MAX; } // (this ring slot is the subframe t + HRING from here on: joined at t + 2 at the earliest)
         if (tid == 64) scal[B_NGL + (parity ^ 1)] = 0;
@@ -576,8 +668,8 @@ __global__ __launch_bounds__(NWB * 64) void batch_kernel(const TrialDev *__restr
             atomicOr(&(BU(bl::GBM) + parity * (GBITS / 32))[(my & (GBITS - 1)) >> 5], 1u << (my & 31));
             const int gp = atomicAdd(&scal[B_NGL + parity], 1);
             if (gp < GLCAP) (BI(bl::GLIST) + parity * GLCAP)[gp] = my; else scal[B_OVF] = 1;
-            const int es_ = (int)((unsigned)(t + 1) & calmask), ep = atomicAdd(&ecnt[es_], 1);
-            if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)ep] = my | CAL_GRANT; else scal[B_OVF] = 1;
+            const int es_ = (int)((unsigned)(t + 1) & calmask), ep = atomicAdd(&ecnt[CR + es_], 1);
+            if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)(calcap - 1 - ep)] = my | CAL_GRANT; else scal[B_OVF] = 1;
             const int fm = BI(bl::FMINP)[bp];
             if ((fm >> 6) == my && fm != INT_MAX) {
                 const int rem = fm & 63;

@@ -656,8 +656,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (std::getenv("PRACH_PRINT_STAMPS")) {
             static const char *const nm[24] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "window-rest", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "phaseA",
                                                "w:phaseA|A-barrier", "w:loads", "w:refill", "t:buckets", "-", "-", "-", "-"};
-            static const char *const nmb[24] = {"head", "joins", "-", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "-", "-", "-",
-                                                "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_batch.hip
+            static const char *const nmb[24] = {"head", "joins", "-", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "b:select", "b:bookkeep", "b:schedule",
+                                                "b:wait-next", "b:stores", "-", "-", "-", "-", "-", "-"}; // prach_batch.hip
             static const char *const nmn[24] = {"head", "publish+gather", "gather-barrier", "resolve(w0)", "resolve-barrier", "passB+A(w0)", "pass-barrier", "-", "r:to-gains", "r:rank+sort", "r:pairing", "-", "-", "-", "-", "-",
                                                 "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_noma.hip, per SUBFRAME (x accessTime = per slot)
             const char *const *const names = noma ? nmn : e->last.rec_mode == CLUSTER_REC_BATCH ? nmb : nm;
