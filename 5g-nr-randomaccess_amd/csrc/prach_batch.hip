@@ -1,30 +1,36 @@
 // prach_batch.hip — the BATCHED regime: one workgroup per trial, thousands of trials in flight (BASELINE configs[2] / [4]: the
-// --times x nUE sweep).  The state of the in-flight trials streams through HBM every subframe, so what a UE costs is what is READ of it
-// and how many instructions are spent on it — in every subframe it merely waits in.
+// --times x nUE sweep).  The state of the in-flight trials lives in HBM, so what a UE costs is what is READ and WRITTEN of it and HOW.
 //
-// Round 3 walked one 32-bit pass word per live UE per subframe (79 % -> 30 % of a subframe; profiles/r03_config3.md).  Round 4: NO WALK.
+// Round 3 walked one 32-bit pass word per live UE per subframe; the first round-4 form replaced the walk by calendars of UE indices and kept one
+// 32-byte record per UE at its own address — and ran, like round 3, at the rate at which an MI355X reads and writes random 32-byte records
+// (profiles/tools/gather_probe.hip: 2.0-2.4e10 records/s from HBM, the kernel: 1.9e10 events/s; extra Philox draws or LDS atomics per event cost
+// nothing, one more scattered store per event 4 %: profiles/r04_grid.md).  Hence this form: THE STATE TRAVELS WITH THE EVENT.
+//
 // A UE in steady contention is bumped every subframe (Beta.c:346,358) and counts one RAR-window subframe each time (Beta.c:245), so when the
-// event body schedules a UE its whole trajectory until its next event is known: matched by preambleCollision scans in [tj, tj + dur), an
-// event at tj + dur (prach_ue_body.h: pw_schedule).  The trial keeps two CALENDARS (time-indexed lists in global memory, their fill counts in LDS):
-//   * the JOIN calendar: at tj the UE adds itself to the per-bucket histogram and lowest-index tables of the subframes tj .. tj + dur - 1 —
-//     a ring of HRING subframes in LDS (dur x 2 LDS atomics, ONCE per contention window instead of two per subframe of the window);
-//   * the EVENT calendar: at tj + dur (window expiry, Msg3, a deferred outcome) the UE's index is in the list of the subframe — that list IS the
-//     event queue of the subframe: complete when the subframe begins (no pass, no barrier in front of the event body), dense (64 UEs per batch).
-// What a subframe costs is therefore its EVENTS (one 32-byte record in, one out, two 4-byte calendar entries in and out), not its live UEs.
-//   * An UL grant (the resolver, Beta.c:336-347) takes a UE out of contention early: the UE goes into the next subframe's event list (bit 31),
-//     into the workgroup's granted set of this subframe (LDS bitmap + list: its other calendar entries of the next subframe are skipped, a later
-//     one is recognised by its generation count), and a granted mid-window UE — necessarily the only member of its bucket — is taken out of the
-//     ring's later subframes by the granting thread (its remaining window rides in the low bits of the lowest-index word).
-//   * Everything about a UE — the 16-byte hot record of prach_device.h plus draw index, preambleTxCounter, failCount, first / second TxTime, the
-//     schedule word — is ONE 32-byte record, read and written only by the event body.
+// event body lets go of a UE its whole trajectory until its next event is known: matched by preambleCollision scans in [tj, tj + dur), an
+// event at tj + dur (prach_ue_body.h: pw_schedule).  The trial keeps, per future subframe (slot = subframe & calmask):
+//   * the EVENT LIST of the subframe: the 32-byte records of the UEs whose next event falls into it, in CHUNKS of 64 records (2 KB, two planes of
+//     16 bytes per UE).  The event body of a subframe reads its chunks — every wavefront-instruction a contiguous kilobyte —, and each wavefront
+//     appends the records it has finished to ITS OWN open chunk of the subframe they are scheduled into (its open chunks and a stack of free chunk
+//     ids sit in three of its vector registers: no shared cursor, nothing to wait for); a full chunk is entered into the subframe's chunk table.
+//     A UE's record is in exactly one place at any time — no random read, no random write, no stale copy;
+//   * the JOIN LIST: the indices of the UEs whose contention window opens in the subframe — at tj the UE adds itself to the per-bucket histogram
+//     and lowest-index tables of the subframes tj .. tj + dur - 1, a ring of 16 subframes in LDS (dur x 2 LDS atomics ONCE per window).
+// What a subframe costs is therefore its EVENTS, streamed, not its live UEs and not random records.
+//   * An UL grant (the resolver, Beta.c:336-347) takes a UE out of contention early.  Its record is somewhere in a later subframe's list, so the grant
+//     is only NOTED — per bucket and subframe, in a ring of the last 16 subframes (LDS) — and applied when the record comes up, as if it had been
+//     looked at one subframe after the grant (nothing happens to a granted UE before Msg3, ten subframes later: hence maxRarWindow <= 11 here); a
+//     granted mid-window UE — necessarily the only member of its bucket — is taken out of the histogram ring's later subframes by the granting
+//     thread (its remaining window rides in the low bits of the lowest-index word), a UE granted in the subframe it was scheduled in skips its join.
+//   * A UE that has finished for good (or whose txTime never comes) is written to its record's home (PD->rec32) — once per UE.
 //   * The event body is prach_ue_body.h (shared with every other kernel); the resolver is prach_cluster.hip's for one workgroup.
-//   * No per-subframe capacity on the resolver's event list or the leaver candidates (they continue in global memory); a calendar list holds
-//     PD->calcap entries (the engine sizes it at nUE / 4, at nUE for small trials) — beyond that the trial is rerun on trial_kernel, reported.
+//   * No per-subframe capacity on the resolver's event list or the leaver candidates (they continue in global memory); the chunk pool and the join
+//     lists are sized by the engine — a trial that exhausts them leaves with PRACH_ERR_INTERNAL and is rerun with full-size ones, reported.
 //   * batch_kernel<16, true>: the same in the reference's own rand() stream (what `prach_sim -t 100` issues per sweep point) — the event body
 //     runs as a count pass + a block-wide prefix over the 64-UE groups + a select pass, see the kernel's head.
 //   * PRACH_FLAG_SECTOR_GRANTS (WithNOMA:626-637): six grant budgets in the grant phase.
-// Limits (the engine falls back to prach::cluster_kernel): nPreamble <= 64, maxRarWindow <= 64 (<= 16 in the two-trials-per-CU shape), < 65 000
-// subframes, backoff + accessTime + maxRarWindow + 70 <= 256 (the calendar's horizon); the reference-stream form: 131 072 UEs.
+// Limits (the engine falls back to prach::cluster_kernel): nPreamble <= 64, maxRarWindow <= 11, < 65 000 subframes, backoff + accessTime +
+// maxRarWindow + 70 <= 256 (the calendar's horizon); the reference-stream form: 131 072 UEs.
 // Reference semantics: RandomAccessSimulatorBeta.c:111-197 / RandomAccessWithNOMA.c:267-351; decomposition: DESIGN.md section 3.
 #include "prach_device.h"
 #include "prach_device_fn.h"
@@ -45,32 +51,26 @@ namespace {
 #define BSTAMP(k) do { } while (0)
 #endif
 
-#ifndef PRACH_B_K1
-#define PRACH_B_K1 1   // (experiment switch) 0: no separate list / short path for "window closes, retransmit" events
-#endif
 #ifndef PRACH_B_W8_WAVES
-#define PRACH_B_W8_WAVES 6 // (experiment switch) wavefronts per SIMD the 512-thread shape is compiled for: 4 = two workgroups per CU, 6 = three
+#define PRACH_B_W8_WAVES 4 // wavefronts per SIMD the 512-thread shape is compiled for: 4 = two workgroups per CU (6 = three: measured level, with spills)
 #endif
 #ifndef PRACH_B_XVALU
 #define PRACH_B_XVALU 0 // (sensitivity experiment) extra Philox draws per event batch, results unused
 #endif
 #ifndef PRACH_B_XLDS
-#define PRACH_B_XLDS 0  // (sensitivity experiment) extra returning LDS atomics per event batch (on a dummy word)
-#endif
-#ifndef PRACH_B_XST
-#define PRACH_B_XST 0   // (sensitivity experiment) extra scattered 4-byte global stores per event batch (into the UE's own record word 7, rewritten right after)
-#endif
-#ifndef PRACH_B_PIPE
-#define PRACH_B_PIPE 1 // (experiment switch) 0: the compiler places the waits for the next batch's loads
+#define PRACH_B_XLDS 0  // (sensitivity experiment) extra returning LDS atomics per event batch (on dummy words)
 #endif
 constexpr int NPB = 64;       // stride of the per-bucket tables (nPreamble <= 64)
 constexpr int BSC = 2048;     // singleton callers per subframe
 constexpr int BGB = 1024;     // grant selection bins
-constexpr int CR = 256;       // calendar slots: the fill counts of the subframes t .. t + 255 (LDS); a trial uses the first calmask + 1 of them
+constexpr int CR = 256;       // calendar slots: the subframes t .. t + 255 (counts in LDS); a trial uses the first calmask + 1 of them
+constexpr int HRING = 16;     // subframes ahead the histogram / lowest-index ring and the grant notes hold: a window lasts maxRarWindow - 1 <= 10 subframes
+constexpr int CHUNK = 128;    // int4 per chunk: plane A [64] (the hot record of prach_device.h), plane B [64] (see BRec)
+constexpr int ROVCAP = 64;    // grants of one subframe beyond the first of their bucket (several singleton callers of one preamble: Beta.c:321-330)
 // Workgroup shapes.  NWB wavefronts per workgroup: 16 (1024 threads, one workgroup = one trial per CU) or 8 (512 threads and an LDS
-// footprint under 80 KB, so that TWO workgroups = two independent trials share a CU: while one waits at a barrier or for its event
-// records, the other one issues).  What is held in LDS per subframe (event list and candidate list continue in global memory; the singleton
-// list BSC, the reset-cycle / crossing-bin lists RCCAP and the granted list are capacities: beyond them the engine reruns the trial on trial_kernel):
+// footprint under 80 KB, so that TWO workgroups = two independent trials share a CU: while one waits at a barrier, the other one issues).
+// What is held in LDS per subframe (event list and candidate list continue in global memory; the singleton list BSC and the
+// reset-cycle / crossing-bin lists RCCAP are capacities: beyond them the engine reruns the trial on trial_kernel):
 template <int NWB> struct BCap {
     static constexpr int EV = NWB == 16 ? 4096 : 1536;    // events of a subframe held in LDS (more: global memory)
 #ifdef PRACH_QCAP
@@ -78,16 +78,14 @@ template <int NWB> struct BCap {
 #else
     static constexpr int CAND = NWB == 16 ? 4096 : 1024;  // early-leaver candidates of a subframe held in LDS (more: global memory)
 #endif
-    static constexpr int HRING = NWB == 16 ? 64 : 16;     // subframes ahead the histogram / lowest-index ring holds: a window lasts maxRarWindow - 1 < HRING subframes
-    static constexpr int GBITS = NWB == 16 ? 32768 : 16384; // granted-UE bitmap (bit = UE index mod GBITS: exact below that many UEs, else a filter in front of the list)
-    static constexpr int GL = NWB == 16 ? 1024 : 512;     // granted UEs of a subframe (list)
 };
 
 constexpr int EVB_CALLER = UEV_CALLER, EVB_RESETCAND = UEV_RESETCAND, EVB_RJOIN = UEV_RJOIN, EVB_LEAVER = 4;
 
-// (the event / candidate / granted counts exist twice, by subframe parity: a wavefront that is already in the next subframe's body appends to the other one)
-enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_OVF /* a calendar list / the granted list is full: the trial leaves */, B_NEV = 8 /* [2] */, B_NCAND = 10 /* [2] */,
-       B_NGL = 12 /* [2] granted UEs */, B_PTC = 14, B_FC, B_SUMT = 16, B_ND = 18, B_JOINS = 20, B_EVENTS = 21, B_NCROSS = 22, B_SGC = 24 /* [24, 30): sectorGrants[6], WithNOMA:260 (PRACH_FLAG_SECTOR_GRANTS) */ };
+// (the event / candidate counts and the free-chunk pool exist twice, by subframe parity: a wavefront that is already in the next subframe's body uses the other one)
+enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_OVF /* the chunk pool, a chunk table or a join list is full: the trial leaves */, B_NEV = 8 /* [2] */, B_NCAND = 10 /* [2] */,
+       B_POOLH = 12 /* [2] free chunk ids in the shared pool's two halves */, B_PTC = 14, B_FC, B_SUMT = 16, B_ND = 18, B_JOINS = 20, B_EVENTS = 21, B_NCROSS = 22, B_BUMP = 23 /* chunks never used yet */,
+       B_SGC = 24 /* [24, 30): sectorGrants[6], WithNOMA:260 (PRACH_FLAG_SECTOR_GRANTS) */, B_NROV = 32 /* [16] grants beyond the first of their bucket, per subframe of the ring */ };
 
 // ---- LDS layout: byte offsets, all compile-time ------------------------------------------------------------------------------------
 template <int NWB> struct BL {
@@ -104,18 +102,18 @@ template <int NWB> struct BL {
     static constexpr int NLV = LCALL + 8 * NPB;            // int [NPB]
     static constexpr int FIE = NLV + 4 * NPB;              // int [NPB]
     static constexpr int FMINP = FIE + 4 * NPB;            // int [NPB] the lowest matched UE of every bucket as the ring held it: index << 6 | subframes of its window still ahead
-    static constexpr int HR = FMINP + 4 * NPB;             // int [HRING][NPB] histogram ring: matched UEs per bucket in the subframes t .. t + HRING - 1 (slot = subframe mod HRING)
-    static constexpr int MR = HR + 4 * C::HRING * NPB;     // int [HRING][NPB] lowest matched index << 6 | remaining window, same ring
-    static constexpr int ECNT = MR + 4 * C::HRING * NPB;   // int [2][CR] entries in the event calendar's list of the subframes t .. (slot = subframe & calmask): [0] "window closes,
-                                                           // retransmit" events, filled from the list's front; [1] every other event, filled from its back
-    static constexpr int JCNT = ECNT + 8 * CR;             // int [CR] ... in the join calendar's
-    static constexpr int GBM = JCNT + 4 * CR;              // unsigned [2][GBITS / 32] granted-UE bitmap, by subframe parity
-    static constexpr int GLIST = GBM + 2 * C::GBITS / 8;   // int [2][GL] granted UEs, by subframe parity
-    static constexpr int CANDL = GLIST + 2 * 4 * C::GL;    // int [CAND] early-leaver candidates: index | old bucket << 20
+    static constexpr int HR = FMINP + 4 * NPB;             // int [HRING][NPB] histogram ring: matched UEs per bucket in the subframes t .. t + HRING - 1 (row = subframe mod HRING)
+    static constexpr int MR = HR + 4 * HRING * NPB;        // int [HRING][NPB] lowest matched index << 6 | remaining window, same ring
+    static constexpr int RG = MR + 4 * HRING * NPB;        // int [HRING][NPB] grant notes: the UE granted as its bucket's (first) singleton caller in the subframes t - 15 .. t, -1 none
+    static constexpr int BM = RG + 4 * HRING * NPB;        // unsigned [NPB] per bucket, bit (subframe mod 16): a grant note exists
+    static constexpr int ROV = BM + 4 * NPB;               // int [HRING][ROVCAP] further grants of a subframe: index | bucket << 20
+    static constexpr int NCHK = ROV + 4 * HRING * ROVCAP;  // int [CR] chunks entered into the event list of the subframes t .. (slot = subframe & calmask)
+    static constexpr int JCNT = NCHK + 4 * CR;             // int [CR] entries in the join list of ...
+    static constexpr int CANDL = JCNT + 4 * CR;            // int [CAND] early-leaver candidates: index | old bucket << 20
     static constexpr int END = CANDL + 4 * C::CAND;
     static_assert(SIDX % 16 == 0 && HR % 16 == 0, "alignment");
 };
-static_assert(BL<8>::END <= 160 * 1024 / 3, "three 512-thread workgroups per CU");
+static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
 // The reference's own rand() stream (GLIBC instantiation, 1024 threads): per 64-UE group of the trial, the lanes that make at least one / two rand()
 // calls in this subframe (two 64-bit masks) and the group's exclusive prefix of calls in index order.  BGG groups = 131 072 UEs at most.
 constexpr int BGG = 2048;
@@ -126,31 +124,21 @@ static_assert(BLG::END <= 160 * 1024 && BLG::GM % 16 == 0, "LDS");
 #define BU(off) (reinterpret_cast<unsigned *>(smem + (off)))
 #define BI2(off) (reinterpret_cast<int2 *>(smem + (off)))
 
-// the 32-byte event record: A = the hot record of prach_device.h {txTime, timer base, nowBackoff, packed}; B = {Philox draw index (24 bits) |
-// generation count of the UE's schedule << 24, preambleTxCounter | failCount << 16, secondTxTime | firstTxTime << 16, the schedule word}
+// the 32-byte record of a UE: A = the hot record of prach_device.h {txTime, timer base, nowBackoff, packed}; B = {Philox draw index (24 bits) | the
+// length of the window it was scheduled with << 24, preambleTxCounter | failCount << 16, secondTxTime | firstTxTime << 16, the UE's index} — in a chunk:
+// A in plane A, B in plane B, at the same position; at home (PD->rec32, finished and idle UEs): word 7 is PW_DONE / PW_IDLE instead of the index
 struct BRec { int4 a, b; };
-__device__ __forceinline__ BRec brec_load(const PRACH_G v4i_t *p) {
-    const v4i_t a = p[0], b = p[1]; // (plain loads and stores: non-temporal ones cost 30 % on config 3 — a record's line is read again soon)
-    BRec r;
-    r.a = make_int4(a.x, a.y, a.z, a.w); r.b = make_int4(b.x, b.y, b.z, b.w);
-    return r;
-}
-__device__ __forceinline__ void brec_store(PRACH_G v4i_t *p, const int4 a, const int4 b) {
-    v4i_t va, vb;
-    va.x = a.x; va.y = a.y; va.z = a.z; va.w = a.w; vb.x = b.x; vb.y = b.y; vb.z = b.z; vb.w = b.w;
-    p[0] = va; p[1] = vb;
-}
+__device__ __forceinline__ int4 ld_i4(const PRACH_G v4i_t *p) { const v4i_t v = *p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_i4(PRACH_G v4i_t *p, const int4 a) { v4i_t v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; *p = v; }
 __device__ __forceinline__ ColdRegs cold_unpack(const int4 b) {
     ColdRegs c;
     c.ptc = b.y & 0xffff; c.fcnt = (int)((unsigned)b.y >> 16); c.stt = b.z & 0xffff; c.ftt = (int)((unsigned)b.z >> 16);
     return c;
 }
-__device__ __forceinline__ int4 cold_pack(const unsigned nd, const unsigned gen, const ColdRegs &c, const unsigned word) {
-    return make_int4((int)((nd & 0xFFFFFFu) | (gen << 24)), (c.ptc & 0xffff) | (c.fcnt << 16), (c.stt & 0xffff) | (c.ftt << 16), (int)word);
+__device__ __forceinline__ int4 cold_pack(const unsigned nd, const unsigned sdur, const ColdRegs &c, const int w7) {
+    return make_int4((int)((nd & 0xFFFFFFu) | (sdur << 24)), (c.ptc & 0xffff) | (c.fcnt << 16), (c.stt & 0xffff) | (c.ftt << 16), w7);
 }
-// calendar entries.  Event calendar: UE index [19:0] | generation [27:20] | bit 31: an UL grant of the previous subframe (always valid).
-// Join calendar: UE index [19:0] | bucket [25:20] | window length [31:26].
-constexpr int CAL_GRANT = (int)0x80000000u;
+// Join list entries: UE index [19:0] | bucket [25:20] | window length [31:26].  Chunk table entries: chunk id [23:0] | records in it [30:24].
 
 } // namespace
 
@@ -164,7 +152,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     static_assert(!GLIBC || NWB == 16, "the reference-stream form exists in the 1024-thread shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using bl = BL<NWB>;
-    constexpr int TB = NWB * 64, BEV = BCap<NWB>::EV, CCAP = BCap<NWB>::CAND, HRING = BCap<NWB>::HRING, GBITS = BCap<NWB>::GBITS, GLCAP = BCap<NWB>::GL;
+    constexpr int TB = NWB * 64, BEV = BCap<NWB>::EV, CCAP = BCap<NWB>::CAND;
     const TrialDev *const PD = params + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nUE = PD->nUE, nP = PD->nP, aT = PD->aT, stop = PD->stop, nGrantUL = PD->nGrantUL, binshift = PD->binshift;
@@ -175,12 +163,16 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     K.maxRar = PD->maxRarWindow; K.maxMsg2 = PD->maxMsg2; K.aT = aT; K.withnoma = variant == PRACH_VARIANT_WITHNOMA_C;
     K.fmP = make_fastmod(nP); K.fmB = make_fastmod(PD->backoff); K.fmA = make_fastmod(aT); K.fm5 = make_fastmod(5);
     const bool withnoma = K.withnoma;
-    PRACH_G v4i_t *const rec32 = (PRACH_G v4i_t *)PD->rec32;     // [nUE][2]
-    PRACH_G int *const ecal = (PRACH_G int *)PD->ecal;           // [calmask + 1][calcap] event calendar
-    PRACH_G int *const jcal = (PRACH_G int *)PD->jcal;           // [calmask + 1][calcap] join calendar
+    PRACH_G v4i_t *const rec32 = (PRACH_G v4i_t *)PD->rec32;     // [nUE][2] a UE's record at home: before it arrives, and once it has finished
+    PRACH_G v4i_t *const chunks = (PRACH_G v4i_t *)PD->chunks;   // [nchunks][CHUNK] the pool of 2 KB chunks
+    PRACH_G int *const ctab = (PRACH_G int *)PD->ctab;           // [calmask + 1][tcap] chunk table: the chunks of every future subframe's event list
+    PRACH_G int *const cpool = (PRACH_G int *)PD->cpool;         // [2][nchunks] shared pool of free chunk ids (what the wavefronts' own stacks cannot take)
+    const int nchunks = PD->nchunks, tcap = PD->tcap;
+    PRACH_G int *const jcal = (PRACH_G int *)PD->jcal;           // [calmask + 1][calcap] join lists
     const int calcap = PD->calcap;
     const unsigned calmask = (unsigned)PD->calmask;
     PRACH_G int *const candg = (PRACH_G int *)PD->qov;           // [nUE] early-leaver candidates of a subframe beyond their LDS part
+    PRACH_G int *const sect_arr = (PRACH_G int *)PD->sector;     // [nUE] (PRACH_FLAG_SECTOR_GRANTS in the reference's stream only) the UE's sector
     const PRACH_G int *const sched = (const PRACH_G int *)PD->sched;
     int *const scal = BI(bl::SCAL);
     int2 *const gev = BI2(bl::GEV);
@@ -189,8 +181,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     auto ev_get = [&](const int k) -> int2 { if (k < BEV) return gev[k]; const v2i_t v = evov[k - BEV]; return make_int2(v.x, v.y); };
     auto ev_set = [&](const int k, const int a, const int b) { if (k < BEV) gev[k] = make_int2(a, b); else store_i2(&evov[k - BEV], a, b); };
     auto ev_kill = [&](const int k) { if (k < BEV) gev[k].y = 0; else evov[k - BEV].y = 0; };
-    int *const ecnt = BI(bl::ECNT), *const jcnt = BI(bl::JCNT);
-    int *const hr = BI(bl::HR), *const mr = BI(bl::MR);
+    int *const nchk = BI(bl::NCHK), *const jcnt = BI(bl::JCNT);
+    int *const hr = BI(bl::HR), *const mr = BI(bl::MR), *const rg = BI(bl::RG), *const rov = BI(bl::ROV);
+    unsigned *const bmk = BU(bl::BM);
     int *const candl = BI(bl::CANDL);
     unsigned *const gm = BU(BLG::GM);  // (GLIBC only) [BGG][4]: lanes with >= 1 call (two words), lanes with 2 calls (two words)
     int *const gpre = BI(BLG::GPRE);   // (GLIBC only) [BGG]
@@ -200,12 +193,11 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
 
     const int totgroups = (nUE + 63) >> 6;
     // calloc + initialUE (Beta.c:78-83)
-    for (int i = tid; i < nUE; i += TB) brec_store(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0), make_int4(0, 0, 0, (int)PW_IDLE));
-    for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; }
-    for (int k = tid; k < CR; k += TB) { ecnt[k] = 0; ecnt[CR + k] = 0; jcnt[k] = 0; }
-    for (int k = tid; k < 2 * GBITS / 32; k += TB) BU(bl::GBM)[k] = 0u;
+    for (int i = tid; i < nUE; i += TB) { st_i4(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0)); st_i4(rec32 + 2 * (size_t)i + 1, make_int4(0, 0, 0, (int)PW_IDLE)); }
+    for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; rg[k] = -1; }
+    for (int k = tid; k < CR; k += TB) { nchk[k] = 0; jcnt[k] = 0; }
     if (tid < NPB) {
-        BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; BI(bl::FMINP)[tid] = INT_MAX;
+        BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; BI(bl::FMINP)[tid] = INT_MAX; bmk[tid] = 0u;
         BI(bl::FCALL)[tid] = INT_MAX; BI(bl::FCALL)[NPB + tid] = INT_MAX; BI(bl::LCALL)[tid] = -1; BI(bl::LCALL)[NPB + tid] = -1;
     }
     if (tid < 64) scal[tid] = 0;
@@ -214,23 +206,70 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
 
     int activeCheck = 0, grantCheck = 0, tlast = -1, time_exit = stop;
     int acNext = sched[0]; // the arrival table's entry of the NEXT access slot: loaded a slot ahead, so that no subframe waits for it (Beta.c:121-134)
-    int why = 0;   // which per-subframe capacity ended the trial (reported)
+    int why = 0;   // which capacity ended the trial (reported)
     unsigned long long steps = 0;
-    int status = (nP > NPB || K.maxRar > HRING || stop > 65000 || (GLIBC && totgroups > BGG) || nUE >= (1 << 20) || calmask >= (unsigned)CR ||
+    int status = (nP > NPB || K.maxRar > 11 || stop > 65000 || (GLIBC && totgroups > BGG) || nUE >= (1 << 20) || calmask >= (unsigned)CR ||
                   PD->backoff + max(aT, 5) + K.maxRar + 70 > (int)calmask + 1) ? PRACH_ERR_UNSUPPORTED : PRACH_OK;
 #ifdef PRACH_STAMPS
     unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
 #endif
-    // was UE i given an UL grant in the subframe whose granted set sits at parity `par`?  (bitmap first; exact list behind it when the trial has more UEs than bits)
-    auto granted_in = [&](const int par, const int i) -> bool {
-        const unsigned *const bm = BU(bl::GBM) + par * (GBITS / 32);
-        if (!((bm[(i & (GBITS - 1)) >> 5] >> (i & 31)) & 1u)) return false;
-        if (nUE <= GBITS) return true;
-        const int n = min(scal[B_NGL + par], GLCAP);
-        const int *const gl = BI(bl::GLIST) + par * GLCAP;
-        bool hit = false;
-        for (int k = 0; k < n; k++) hit = hit || gl[k] == i;
-        return hit;
+    // ---- this wavefront's chunk bookkeeping, in three vector registers (lane = table position) and one scalar ----
+    int o_id = -1;   // lane k: the chunk this wavefront is filling for the subframe te with (te & 63) == k; -1: none
+    int o_meta = 0;  // lane k: te (16 bits) | records in it << 16
+    int stash = 0;   // lanes [0, sp): free chunk ids (a chunk is free as soon as its records are in registers; the wavefront that read it fills it again)
+    int sp = 0;
+    int pool_parity = 0; // (this subframe's parity, for the shared pool's halves)
+    auto chunk_free = [&](const int id) __attribute__((always_inline)) { // wave-uniform
+        if (sp < 64) { stash = lane == sp ? id : stash; sp++; }
+        else if (lane == 0) { const int h = atomicAdd(&scal[B_POOLH + pool_parity], 1); if (h >= 0 && h < nchunks) cpool[(size_t)pool_parity * (size_t)nchunks + (size_t)h] = id; }
+    };
+    auto chunk_alloc = [&]() __attribute__((always_inline)) -> int { // wave-uniform
+        if (sp > 0) { sp--; return __builtin_amdgcn_readlane(stash, sp); }
+        int id = 0;
+        if (lane == 0) { // the shared pool's half that was filled in the previous subframe, then chunks never used before
+            const int side = pool_parity ^ 1;
+            const int h = atomicSub(&scal[B_POOLH + side], 1);
+            if (h > 0 && h <= nchunks) id = __hip_atomic_load(cpool + (size_t)side * (size_t)nchunks + (size_t)(h - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else {
+                id = atomicAdd(&scal[B_BUMP], 1);
+                if (id >= nchunks - 1) { scal[B_OVF] = 1; id = nchunks - 1; } // (the pool's last chunk takes what no longer matters: the trial leaves behind S2)
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(id);
+    };
+    auto chunk_close = [&](const int id, const int te, const int count) __attribute__((always_inline)) { // wave-uniform: the chunk joins subframe te's event list
+        if (lane == 0) {
+            const int sl = (int)((unsigned)te & calmask);
+            const int seq = atomicAdd(&nchk[sl], 1);
+            if (seq < tcap) ctab[(size_t)sl * (size_t)tcap + (size_t)seq] = id | (count << 24);
+            else scal[B_OVF] = 1;
+        }
+    };
+    // this wavefront's open chunk of subframe te, if it has one, joins that subframe's list (behind S1 of te - 1: nothing is appended to it any more)
+    auto chunk_flush = [&](const int te) __attribute__((always_inline)) {
+        const int k = te & 63;
+        const int id = __builtin_amdgcn_readlane(o_id, k), meta = __builtin_amdgcn_readlane(o_meta, k);
+        if (id >= 0 && (meta & 0xFFFF) == (te & 0xFFFF)) {
+            chunk_close(id, te, meta >> 16);
+            o_id = lane == k ? -1 : o_id;
+        }
+    };
+    // was UE i (bucket p) given an UL grant in one of the subframes [s0, s1] (s1 - s0 < 16, s1 at most 15 subframes old)?  The subframe, or -1.
+    auto granted_at = [&](const int i, const int p, const int s0, const int s1) -> int {
+        const unsigned m = bmk[p];
+        int found = -1;
+        if (m) {
+            for (int s = s1; s >= s0 && s >= 0; s--) {
+                if ((m >> (s & 15)) & 1u) {
+                    if (rg[(s & 15) * NPB + p] == i) found = s;
+                    else {
+                        const int n = min(scal[B_NROV + (s & 15)], ROVCAP);
+                        for (int k = 0; k < n; k++) if (rov[(s & 15) * ROVCAP + k] == (i | (p << 20))) found = s;
+                    }
+                }
+            }
+        }
+        return found;
     };
 
     for (int t = 0; t < stop && status == PRACH_OK; t++) {
@@ -246,14 +285,15 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             acNext = sched[t / aT + 1]; // (the table has maxTime / accessTime + 2 entries: prach_engine.hip)
         }
         const int parity = t & 1;
+        pool_parity = parity;
         int *const fcallA = BI(bl::FCALL) + parity * NPB, *const lcallA = BI(bl::LCALL) + parity * NPB;
         int *const fcallB = BI(bl::FCALL) + (parity ^ 1) * NPB, *const lcallB = BI(bl::LCALL) + (parity ^ 1) * NPB;
-        const int slot = (int)((unsigned)t & calmask);                       // this subframe's calendar lists
+        const int slot = (int)((unsigned)t & calmask);                       // this subframe's lists
         int *const histx = hr + (t & (HRING - 1)) * NPB, *const mlocx = mr + (t & (HRING - 1)) * NPB; // ... and its histogram / lowest matched index << 6 | window left
-        const int n1 = ecnt[slot], ne = ecnt[CR + slot], nj = jcnt[slot];     // complete: every entry was made in an earlier subframe (the grants' behind S6)
-        const int qn = ne + (activeCheck - prevAC);                           // this access slot's arrivals (Beta.c:136-146) are events too: virtual entries behind the list's
-        PRACH_G int *const elist = ecal + (size_t)slot * (size_t)calcap;      // retransmission events [0, n1) from the front, the other ne from the back
-        if (n1 + ne > calcap) scal[B_OVF] = 1;                                // (the two ends have met: the trial leaves behind S2 and is rerun with longer lists)
+        const int nch = nchk[slot], nj = jcnt[slot];                         // complete: every chunk was entered, every join listed in an earlier subframe
+        const int narr = activeCheck - prevAC;                               // this access slot's arrivals (Beta.c:136-146) are events too: batches behind the chunks
+        const int nb = nch + ((narr + 63) >> 6);
+        const PRACH_G int *const clist = ctab + (size_t)slot * (size_t)tcap;
         BSTAMP(0); // loop head
 
         // ================= joins: UEs whose contention window opens in this subframe enter the ring's subframes t .. t + dur - 1 =================
@@ -263,7 +303,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             if (q < nj) je = jcal[(size_t)slot * (size_t)calcap + (size_t)q];
             const int i = je & 0xFFFFF, p = (je >> 20) & 63;
             int dur = (int)((unsigned)je >> 26);
-            if (q >= nj || granted_in(parity ^ 1, i)) dur = 0; // (granted in the subframe before: out of contention, Beta.c:338-343)
+            if (q >= nj || granted_at(i, p, t - 1, t - 1) >= 0) dur = 0; // (granted in the subframe it was scheduled in: out of contention, Beta.c:338-343)
             const int dmax = wave_max(dur);
             for (int k = 0; k < dmax; k++) {
                 if (k < dur) {
@@ -276,28 +316,29 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         BSTAMP(1); // joins
         BSTAMP(2);
 
-        // ================= the event body: this subframe's event list, 64 UEs at a time =================
+        // ================= the event body: this subframe's event list, one chunk (64 UEs) at a time =================
         {
             int c_succ = 0, c_contf = 0;
             const int tmod = t % aT;
             const CallTables tab{fcallB, lcallB};
-            // The loop over a list's batches is written for gfx950's ONE in-order memory counter (loads and stores complete in issue order as far as
-            // s_waitcnt vmcnt can tell): at the top of a batch the records of the NEXT batch and the list entries of the one after are requested; they are
-            // waited for once, right before this batch's stores are issued (pipe_sync: by then they have had the whole batch to arrive), and the stores then
-            // have the next batch's compute phase to complete before anything waits again.  (Waiting at the top of the next batch instead — where the
-            // compiler puts it — waits for the scattered stores as well: measured, that was most of the event body's time under load.)
-            int pe_n2 = 0;      // list entry of this lane two batches ahead
-            BRec pR_n;          // record of this lane's UE in the next batch
+            // The loop over the list's batches is written for gfx950's ONE in-order memory counter (loads and stores complete in issue order as far as
+            // s_waitcnt vmcnt can tell): at the top of a batch the records of the NEXT batch and the chunk-table entry of the one after are requested; they
+            // are waited for once, right before this batch's stores are issued (pipe_sync), and the stores then have the next batch's compute phase to complete.
+            int pd_n2 = 0;      // chunk-table entry two batches ahead (wave-uniform value in a vector register)
+            BRec pR_n;          // this lane's record in the next batch
             pR_n.a = pR_n.b = make_int4(0, 0, 0, 0);
             auto pipe_sync = [&]() __attribute__((always_inline)) {
-                if (PRACH_B_PIPE) asm volatile("" :: "v"(pR_n.a.x), "v"(pR_n.a.y), "v"(pR_n.a.z), "v"(pR_n.a.w), "v"(pR_n.b.x), "v"(pR_n.b.y), "v"(pR_n.b.z), "v"(pR_n.b.w), "v"(pe_n2));
+                asm volatile("" :: "v"(pR_n.a.x), "v"(pR_n.a.y), "v"(pR_n.a.z), "v"(pR_n.a.w), "v"(pR_n.b.x), "v"(pR_n.b.y), "v"(pR_n.b.z), "v"(pR_n.b.w), "v"(pd_n2));
             };
-            auto entry_other = [&](const int q) -> int { return q < qn ? (q < ne ? elist[calcap - 1 - q] : prevAC + (q - ne)) : 0; }; // (arrivals: virtual entries)
-            auto entry_retx = [&](const int q) -> int { return q < n1 ? elist[q] : 0; };
-            auto rec_of = [&](const int e) -> BRec { return brec_load(rec32 + 2 * (size_t)(e & 0xFFFFF)); }; // (record 0 is always mapped: an idle lane loads it and ignores it)
-            // what follows selectPreamble / requestResourceAllocation for every event UE: bucket bookkeeping, special events for the resolver, the UE's schedule
-            auto finish = [&](const bool v, const int i, UeState &u, ColdRegs &cold, const unsigned nd, const unsigned gen, const UeOut &o) __attribute__((always_inline)) {
-                BSTAMP(13); // (fine stamps of the diagnostic build: select logic)
+            auto desc_of = [&](const int b) -> int { return b < nch ? clist[b] : 0; }; // (arrival batches have no chunk)
+            auto recs_of = [&](const int d, const int b) -> BRec { // (every lane loads: chunk 0 is always mapped)
+                BRec R;
+                const PRACH_G v4i_t *const c = chunks + (size_t)(b < nch ? (d & 0xFFFFFF) : 0) * CHUNK;
+                R.a = ld_i4(c + lane); R.b = ld_i4(c + 64 + lane);
+                return R;
+            };
+            // what follows selectPreamble / requestResourceAllocation for every event UE: bucket bookkeeping, special events for the resolver, the UE's next schedule
+            auto finish = [&](const bool v, const int i, UeState &u, ColdRegs &cold, const unsigned nd, const UeOut &o) __attribute__((always_inline)) {
                 if (PRACH_B_XVALU) { // (sensitivity experiment: never changes a result)
                     int x_ = 0;
 #pragma unroll
@@ -307,14 +348,10 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                 if (PRACH_B_XLDS) {
                     int y_ = 0;
 #pragma unroll
-                    for (int k_ = 0; k_ < PRACH_B_XLDS; k_++) y_ += atomicAdd(&scal[40 + (k_ & 7)], 1);
+                    for (int k_ = 0; k_ < PRACH_B_XLDS; k_++) y_ += atomicAdd(&scal[50 + (k_ & 7)], 1);
                     if (y_ == 0x7fffffff) scal[B_OVF] = 3;
                 }
-                if (PRACH_B_XST) {
-#pragma unroll
-                    for (int k_ = 0; k_ < PRACH_B_XST; k_++) if (v) reinterpret_cast<PRACH_G int *>(rec32)[8 * (size_t)i + 7] = k_;
-                }
-                // ---- bucket bookkeeping (this subframe's ring slot; an event UE has nothing in the later ones: window left = 0) ----
+                // ---- bucket bookkeeping (this subframe's ring row; an event UE has nothing in the later ones: window left = 0) ----
                 if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
                 if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i << 6);
                 if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i << 6);
@@ -337,69 +374,91 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                         }
                     }
                 }
-                BSTAMP(14); // bucket bookkeeping, special events
-                // the UE's schedule from here (prach_ue_body.h): matched in [tj, tj + dur), its next event at tj + dur — into the calendars
-                bool k1 = false;
+                // the UE's schedule from here (prach_ue_body.h): matched in [tj, tj + dur), its next event at tj + dur
                 unsigned word = PW_IDLE;
-                if (v) word = pw_schedule(u, t, K.maxRar, K.maxMsg2, k1);
-                if (GLIBC || !PRACH_B_K1) k1 = false; // (the reference-stream form runs every event through the count / select passes)
-                const unsigned gen1 = (gen + 1u) & 0xFFu;
+                if (v) word = pw_schedule(u, t, K.maxRar);
                 const unsigned tjn = word & 0xFFFFu, durn = (word >> 16) & 0x3Fu;
-                const bool sched_ = v && tjn != 0xFFFFu; // (0xFFFF: finished for good, or a txTime that never comes — Beta.c:167)
-                // list positions: one returning LDS atomic per lane and list, both issued before either is waited for (the UEs of a batch go to a handful of
-                // subframes — txTime is aligned to the access slots — so the lanes meet on a few words: ~64 LDS cycles each, but ONE round trip; a wavefront-
-                // aggregated form, one atomic per distinct subframe, measured slower: five dependent round trips)
-                const int js = (int)(tjn & calmask), es_ = (int)((tjn + durn) & calmask);
-                int jp = 0, ep = 0;
+                const bool sched_ = v && tjn != 0xFFFFu; // (0xFFFF: finished for good, or a txTime that never comes — Beta.c:167: the record goes home)
+                const int te = (int)(tjn + durn);        // the subframe of its next event
+                int jp = 0;
+                const int js = (int)(tjn & calmask);
                 if (sched_ && durn > 0u) jp = atomicAdd(&jcnt[js], 1);
-                if (sched_) ep = atomicAdd(&ecnt[k1 ? es_ : CR + es_], 1);
-                BSTAMP(15); // schedule, list positions
-                pipe_sync(); // the next batch's records and the entries behind them have arrived: from here on only stores are issued
-                BSTAMP(16); // wait for the next batch
-                if (v) brec_store(rec32 + 2 * (size_t)i, pack(u), cold_pack(nd, gen1, cold, word));
+                // where the record goes: this wavefront's open chunk of subframe te (one round per distinct te of the batch: txTime is aligned to the access slots)
+                int cid = 0, cpos = 0;
+                {
+                    unsigned long long todo = __ballot(sched_);
+                    while (todo) {
+                        const int te0 = __builtin_amdgcn_readlane(te, __ffsll((long long)todo) - 1);
+                        const unsigned long long mm = __ballot(sched_ && te == te0);
+                        const int c = __popcll(mm), k = te0 & 63;
+                        int id = __builtin_amdgcn_readlane(o_id, k);
+                        const int meta = __builtin_amdgcn_readlane(o_meta, k);
+                        int fill = meta >> 16;
+                        if (id >= 0 && (meta & 0xFFFF) != (te0 & 0xFFFF)) { chunk_close(id, meta & 0xFFFF, fill); id = -1; } // (another subframe sits at this table position: it goes to its list as it is)
+                        if (id < 0) { id = chunk_alloc(); fill = 0; }
+                        const int room = 64 - fill;
+                        int id2 = -1;
+                        if (c > room) id2 = chunk_alloc();
+                        if ((mm >> lane) & 1ull) {
+                            const int rank = __popcll(mm & lanemask_lt(lane));
+                            if (rank < room) { cid = id; cpos = fill + rank; } else { cid = id2; cpos = rank - room; }
+                        }
+                        if (c >= room) { chunk_close(id, te0, 64); id = id2; fill = c - room; } // (id2 = -1, fill = 0 when it is exactly full)
+                        else fill += c;
+                        o_id = lane == k ? id : o_id;
+                        o_meta = lane == k ? ((te0 & 0xFFFF) | (fill << 16)) : o_meta;
+                        todo &= ~mm;
+                    }
+                }
+                pipe_sync(); // the next batch's records and the entry behind them have arrived: from here on only stores are issued
                 if (sched_) {
+                    PRACH_G v4i_t *const c = chunks + (size_t)cid * CHUNK + cpos;
+                    st_i4(c, pack(u)); st_i4(c + 64, cold_pack(nd, durn, cold, i));
                     if (durn > 0u) {
                         if (jp < calcap) jcal[(size_t)js * (size_t)calcap + (size_t)jp] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
                         else scal[B_OVF] = 1;
                     }
-                    if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)(k1 ? ep : calcap - 1 - ep)] = (int)((unsigned)i | (gen1 << 20));
-                    else scal[B_OVF] = 1;
+                } else if (v) { // home: finished for good (or never to be looked at again)
+                    st_i4(rec32 + 2 * (size_t)i, pack(u)); st_i4(rec32 + 2 * (size_t)i + 1, cold_pack(nd, 0u, cold, (int)word));
                 }
-                BSTAMP(17); // stores
             };
             // MODE 0: Philox, everything in one pass.  MODE 1 (GLIBC): the count pass — nothing is stored but the calling lanes.  MODE 2 (GLIBC): the full
             // body with the draws at their stream positions (sbase: position of the subframe's first call of the UE loop).
             auto body_pass = [&](auto MODE_, const unsigned long long sbase) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(MODE_)::value;
-                constexpr int ST = NWB * 64;
-                int e_c = entry_other(w * 64 + lane), e_n = entry_other(w * 64 + ST + lane);
-                BRec R_c = rec_of(e_c);
-                asm volatile("" :: "v"(R_c.a.x), "v"(R_c.a.y), "v"(R_c.a.z), "v"(R_c.a.w), "v"(R_c.b.x), "v"(R_c.b.y), "v"(R_c.b.z), "v"(R_c.b.w), "v"(e_n)); // (the first batch is waited for HERE, not at every batch's top)
-                for (int q0 = w * 64; q0 < qn; q0 += ST) {
-                    if (q0 + ST < qn) { pR_n = rec_of(e_n); pe_n2 = entry_other(q0 + 2 * ST + lane); } // in flight while this batch is worked on
-                    const int e = e_c;
-                    const int i = e & 0xFFFFF;
-                    const bool granted = e < 0;
-                    const bool arrival = q0 + lane >= ne;
+                int d_c = desc_of(w), d_n = desc_of(w + NWB);
+                BRec R_c = recs_of(d_c, w);
+                asm volatile("" :: "v"(R_c.a.x), "v"(R_c.a.y), "v"(R_c.a.z), "v"(R_c.a.w), "v"(R_c.b.x), "v"(R_c.b.y), "v"(R_c.b.z), "v"(R_c.b.w), "v"(d_n)); // (the first batch is waited for HERE, not at every batch's top)
+                for (int b = w; b < nb; b += NWB) {
+                    if (b + NWB < nb) { pR_n = recs_of(d_n, b + NWB); pd_n2 = desc_of(b + 2 * NWB); } // in flight while this batch is worked on
+                    const bool arrival = b >= nch;
+                    const int dcu = __builtin_amdgcn_readfirstlane(d_c);
                     BRec R = R_c;
+                    if (!arrival && MODE != 1) chunk_free(dcu & 0xFFFFFF); // its records are in registers: the chunk can be filled again (by this wavefront, below)
                     // (the next batch moves into place at the END of this one, behind pipe_sync: a register move of a value still in flight would wait for it here)
-                    auto rotate = [&]() __attribute__((always_inline)) { e_c = e_n; e_n = pe_n2; R_c = pR_n; };
-                    const unsigned gen = (unsigned)R.b.x >> 24;
-                    // An entry counts if it is the UE's current one: a grant entry always; any other one not when the UE was granted in the subframe before (its
-                    // grant entry does the work) and not when the UE has been rescheduled since the entry was made (a grant took it out of its window early)
-                    bool v = q0 + lane < qn;
-                    if (v && !granted && !arrival) v = (unsigned)((e >> 20) & 0xFF) == gen && !granted_in(parity ^ 1, i);
-                    if (!v) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
+                    auto rotate = [&]() __attribute__((always_inline)) { d_c = d_n; d_n = pd_n2; R_c = pR_n; };
+                    bool v = arrival ? prevAC + (b - nch) * 64 + lane < activeCheck : lane < (dcu >> 24);
+                    if (!v || arrival) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
+                    const int i = arrival ? prevAC + (b - nch) * 64 + lane : (R.b.w & 0xFFFFF);
                     UeState u = unpack(R.a);
                     ColdRegs cold = cold_unpack(R.b);
                     unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
-                    if (v) pw_catch_up(u, (unsigned)R.b.w, granted, i, t, K.fmA, tab);
-                    if (v && arrival && u.act == ACT_IDLE) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
+                    const int sdur = (int)((unsigned)R.b.x >> 24);
+                    // an UL grant noted since the UE was scheduled (Beta.c:338-343) is applied as if the UE had been looked at one subframe after it: nothing else
+                    // happens to a granted UE before its Msg3, ten subframes later
+                    int tcu = t;
+                    bool granted = false;
+                    if (v && !arrival && u.act == ACT_M1 && u.pre != 0) {
+                        const int gs = granted_at(i, u.pre - 1, t - sdur - 1, t - 1);
+                        if (gs >= 0) { granted = true; tcu = gs + 1; }
+                    }
+                    if (v && !arrival) pw_catch_up(u, pw_make(t - sdur, sdur, 0), granted, i, tcu, K.fmA, tab);
+                    if (v && arrival) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
                         ue_activate(u, i, t, cold);
                         if (withnoma) nd = 2;
-                        // the reference's stream has no per-UE draw index: the record's word keeps the UE's sector instead, fixed by the first of its two
-                        // activation calls (WithNOMA:393-410), which sit at the head of this subframe's calls in index order (read in the select pass: the window has been checked)
-                        if (GLIBC && sectors && MODE == 2) nd = (unsigned)sector_of_draw(stream[base + 2ull * (unsigned long long)(i - prevAC)]);
+                        // the reference's stream: the UE's sector is fixed by the first of its two activation calls (WithNOMA:393-410), which sit at the head of this
+                        // subframe's calls in index order (read in the select pass: the window has been checked) — kept per UE for the grant phase (PD->sector)
+                        if (GLIBC && sectors && MODE == 2) sect_arr[i] = sector_of_draw(stream[base + 2ull * (unsigned long long)(i - prevAC)]);
                     }
                     const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
                     const int g_ = i >> 6, ln = i & 63;
@@ -426,38 +485,10 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                         nd += (unsigned)pl.need;
                     }
                     const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
-                    finish(v, i, u, cold, nd, gen, o);
+                    finish(v, i, u, cold, nd, o);
                     rotate();
                 }
             };
-            // "the RAR window closes, retransmit" (prach_ue_body.h ue_window_retx): the events listed at the front of the subframe's list, one short path for all 64 lanes
-            if (!GLIBC) {
-                constexpr int ST = NWB * 64;
-                const int qs = (NWB - 1 - w) * 64; // (from the last wavefront down: the first ones have the most batches of the other list)
-                int e_c = entry_retx(qs + lane), e_n = entry_retx(qs + ST + lane);
-                BRec R_c = rec_of(e_c);
-                asm volatile("" :: "v"(R_c.a.x), "v"(R_c.a.y), "v"(R_c.a.z), "v"(R_c.a.w), "v"(R_c.b.x), "v"(R_c.b.y), "v"(R_c.b.z), "v"(R_c.b.w), "v"(e_n));
-                for (int q0 = qs; q0 < n1; q0 += ST) {
-                    if (q0 + ST < n1) { pR_n = rec_of(e_n); pe_n2 = entry_retx(q0 + 2 * ST + lane); }
-                    const int e = e_c;
-                    const int i = e & 0xFFFFF;
-                    BRec R = R_c;
-                    const unsigned gen = (unsigned)R.b.x >> 24;
-                    const bool v = q0 + lane < n1 && (unsigned)((e >> 20) & 0xFF) == gen && !granted_in(parity ^ 1, i); // (as in body_pass)
-                    if (!v) { R.a = make_int4(0, 0, 0, ACT_M1 | (1 << PK_PRE_SHIFT)); R.b = make_int4(0, 0, 0, (int)pw_make(t, 0, 0)); }
-                    UeState u = unpack(R.a);
-                    ColdRegs cold = cold_unpack(R.b);
-                    unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
-                    const int d1 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd, (unsigned)nUE, (unsigned)variant);
-                    nd += 1u;
-                    bool ok;
-                    UeOut o = ue_window_retx(u, (unsigned)R.b.w, d1, i, t, K, cold, ok);
-                    if (v && !ok) scal[B_OVF] = 2; // (a record that is not in the state its list promises: reported, the trial is rerun on trial_kernel)
-                    if (!v) { o.evtype = UEV_NONE; o.member_pre = false; o.eclass = false; u.pend = PEND_NONE; }
-                    finish(v, i, u, cold, nd, gen, o);
-                    e_c = e_n; e_n = pe_n2; R_c = pR_n; // (behind pipe_sync: the next batch moves into place)
-                }
-            }
             if (!GLIBC) body_pass(std::integral_constant<int, 0>{}, 0ull);
             else {
                 // activateUEs' two rand() calls per arrival (WithNOMA:393-394) come first in the subframe, in index order; nothing reads them here
@@ -497,11 +528,12 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             }
         }
         BSTAMP(3); // event body
-        __syncthreads(); // S1: histogram / lowest callers / candidate list are complete; the caller tables of t - 1 and the granted set of t - 1 are free
+        __syncthreads(); // S1: histogram / lowest callers / candidate list are complete; the caller tables of t - 1 are free; nothing is appended to subframe t + 1's list any more
         BSTAMP(4);
 
         // early leavers below the bucket's lowest caller are the only ones a rank can need
         {
+            chunk_flush(t + 1); // this wavefront's open chunk of the next subframe joins that subframe's list
             const int ncand = scal[B_NCAND + parity];
             for (int k0 = w * 64; k0 < ncand; k0 += TB) {
                 const int k = k0 + lane;
@@ -515,36 +547,28 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     if ((lm >> lane) & 1ull) ev_set(b_ev + __popcll(lm & lanemask_lt(lane)), ci, EVB_LEAVER | (cp << 4));
                 }
             }
-            if (GLIBC) // every draw of this subframe has been read: the marks of the groups the event UEs are in can go
-                for (int q = tid; q < qn; q += TB) {
-                    const int i = q < ne ? (elist[calcap - 1 - q] & 0xFFFFF) : prevAC + (q - ne);
-                    *reinterpret_cast<uint4 *>(&gm[4 * (i >> 6)]) = make_uint4(0u, 0u, 0u, 0u);
-                }
-            { // the granted set of subframe t - 1 has been used by every join and every event of this subframe: empty it (bit by bit, from its list)
-                const int par = parity ^ 1;
-                const int n = min(scal[B_NGL + par], GLCAP);
-                unsigned *const bm = BU(bl::GBM) + par * (GBITS / 32);
-                const int *const gl = BI(bl::GLIST) + par * GLCAP;
-                for (int k = tid; k < n; k += TB) bm[(gl[k] & (GBITS - 1)) >> 5] = 0u;
-            }
+            if (GLIBC) // every draw of this subframe has been read: the marks go (all of them: 2 x 16 bytes per thread)
+                for (int k = tid; k < BGG; k += TB) *reinterpret_cast<uint4 *>(&gm[4 * k]) = make_uint4(0u, 0u, 0u, 0u);
             if (tid < NPB) { // this workgroup's histogram / lowest callers ARE the totals (only read here: the filter above reads them too)
                 lcallB[tid] = -1; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0;
                 const int m_ = mlocx[tid];
                 BI(bl::TOTAL)[tid] = histx[tid]; fcallA[tid] = m_ == INT_MAX ? INT_MAX : (m_ >> 6); BI(bl::FMINP)[tid] = m_;
+                // the grant notes of subframe t - 16 make room for this subframe's (no record scheduled that long ago is still on its way)
+                rg[(t & 15) * NPB + tid] = -1; bmk[tid] &= ~(1u << (t & 15));
             }
             if (tid == 0) {
-                scal[B_EVENTS] += qn + n1; scal[B_JOINS] += nj; // (reported, never read by the simulation)
-                scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0;
-                ecnt[slot] = 0; ecnt[CR + slot] = 0; jcnt[slot] = 0; // (this slot is the subframe t + calmask + 1 from here on: nothing is scheduled that far ahead)
+                scal[B_EVENTS] += nch * 64 + narr; scal[B_JOINS] += nj; // (reported, never read by the simulation: records read, whole chunks)
+                scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0; scal[B_NROV + (t & 15)] = 0;
+                nchk[slot] = 0; jcnt[slot] = 0; // (this slot is the subframe t + calmask + 1 from here on: nothing is scheduled that far ahead)
+                if (scal[B_POOLH + (parity ^ 1)] < 0) scal[B_POOLH + (parity ^ 1)] = 0; // (the half that was drawn from in this subframe takes the next subframe's free chunks)
             }
         }
         BSTAMP(5); // leaver filter
         __syncthreads(); // S2
         BSTAMP(6);
-        if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = scal[B_OVF] == 2 ? 6 : 5; time_exit = t; break; } // a calendar list (or the granted list, a subframe ago) was full
+        if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = scal[B_OVF] == 1 ? 5 : 6; time_exit = t; break; } // the chunk pool, a chunk table or a join list was full
         const int N = scal[B_NEV + parity];
-        if (tid < NPB) { histx[tid] = 0; mlocx[tid] = INT_MAX; } // (this ring slot is the subframe t + HRING from here on: joined at t + 2 at the earliest)
-        if (tid == 64) scal[B_NGL + (parity ^ 1)] = 0;
+        if (tid < NPB) { histx[tid] = 0; mlocx[tid] = INT_MAX; } // (this ring row is the subframe t + HRING from here on: joined at t + 2 at the earliest)
         const int nsucc_tot = scal[B_NSUCC];
         // classify the events against the lowest DEFINITE caller of every bucket
         for (int k = tid; k < N; k += TB) {
@@ -661,15 +685,16 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         const int ns = scal[B_NS];
         if (ns > BSC) { status = PRACH_ERR_INTERNAL; why = 3; time_exit = t; break; }
         const int Gr = max(0, nGrantUL - 1 - grantCheck); // Beta.c:336-347
-        // An UL grant (Beta.c:338-343) for the singleton caller `my` of bucket bp: into this subframe's granted set and the next subframe's event list; a
-        // mid-window UE (the bucket's lowest matched index as the ring held it, with subframes of its window still ahead) leaves the ring's later
+        // An UL grant (Beta.c:338-343) for the singleton caller `my` of bucket bp: NOTED (its record is in some later subframe's list and takes the grant when it
+        // comes up); a mid-window UE (the bucket's lowest matched index as the ring held it, with subframes of its window still ahead) leaves the ring's later
         // subframes — it was the bucket's only member, so its contributions there are exactly one count and the lowest index
         auto grant = [&](const int my, const int bp) {
-            atomicOr(&(BU(bl::GBM) + parity * (GBITS / 32))[(my & (GBITS - 1)) >> 5], 1u << (my & 31));
-            const int gp = atomicAdd(&scal[B_NGL + parity], 1);
-            if (gp < GLCAP) (BI(bl::GLIST) + parity * GLCAP)[gp] = my; else scal[B_OVF] = 1;
-            const int es_ = (int)((unsigned)(t + 1) & calmask), ep = atomicAdd(&ecnt[CR + es_], 1);
-            if (ep < calcap) ecal[(size_t)es_ * (size_t)calcap + (size_t)(calcap - 1 - ep)] = my | CAL_GRANT; else scal[B_OVF] = 1;
+            const int row = t & 15;
+            if (atomicCAS(&rg[row * NPB + bp], -1, my) != -1) { // (a further singleton caller of the same preamble in this subframe)
+                const int gp = atomicAdd(&scal[B_NROV + row], 1);
+                if (gp < ROVCAP) rov[row * ROVCAP + gp] = my | (bp << 20); else scal[B_OVF] = 2;
+            }
+            atomicOr(&bmk[bp], 1u << row);
             const int fm = BI(bl::FMINP)[bp];
             if ((fm >> 6) == my && fm != INT_MAX) {
                 const int rem = fm & 63;
@@ -682,7 +707,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         };
         // a caller's sector: Philox — a function of the UE's own first activation draw, recomputed; the reference's stream — kept in the UE's record
         auto sector_of = [&](const int my) -> int {
-            if (GLIBC) return rec32[2 * (size_t)my + 1].x & 0xFF;
+            if (GLIBC) return sect_arr[my];
             return sector_of_draw(philox_draw31(seed_lo, seed_hi, (unsigned)my, 0u, (unsigned)nUE, (unsigned)variant));
         };
         if (sectors) {
@@ -811,32 +836,60 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         }
         grantCheck += ns;
         BSTAMP(11); // grants
-        if ((Gr > 0 || sectors) && ns > 0) __syncthreads(); // S6: the grants are in the next subframe's event list and in the granted set before that subframe begins
+        if ((Gr > 0 || sectors) && ns > 0) __syncthreads(); // S6: the grant notes are complete before the next subframe's joins and events look for them
         BSTAMP(12);
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }
     __syncthreads();
-    if (status == PRACH_OK && scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = 5; time_exit = tlast; } // (raised by the last subframe's grants)
+    if (status == PRACH_OK && scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = scal[B_OVF] == 1 ? 5 : 6; time_exit = tlast; } // (raised by the last subframe's grants)
 
-    // ---- the state after the last subframe (deferred outcome + the subframes a UE was matched in since its record was written),
-    // end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508)
+    // ---- the state after the last subframe.  Records still on their way (in some later subframe's list, or in a wavefront's open chunk) go home first: the
+    // deferred outcome of the last subframe (or the grant noted for them) and the subframes they were matched in since they were scheduled are applied, as
+    // the event body would have (pw_catch_up).  Then end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of every UE from its home record.
     const int tend = tlast + 1;
-    {
+    if (status == PRACH_OK && tlast >= 0) {
+        for (int k = 0; k < 64; k++) { // every open chunk of this wavefront joins its subframe's list
+            const int id = __builtin_amdgcn_readlane(o_id, k), meta = __builtin_amdgcn_readlane(o_meta, k);
+            if (id >= 0) chunk_close(id, meta & 0xFFFF, meta >> 16);
+        }
+        __syncthreads();
         const CallTables tab{BI(bl::FCALL) + (tlast & 1) * NPB, BI(bl::LCALL) + (tlast & 1) * NPB};
+        for (int sl = 0; sl <= (int)calmask; sl++) {
+            const int n = min(nchk[sl], tcap);
+            const int te = tend + (int)(((unsigned)sl - (unsigned)tend) & calmask); // the subframe this slot stands for
+            for (int b = w; b < n; b += NWB) {
+                const int d = ctab[(size_t)sl * (size_t)tcap + (size_t)b];
+                const PRACH_G v4i_t *const c = chunks + (size_t)(d & 0xFFFFFF) * CHUNK;
+                if (lane < (d >> 24)) {
+                    const int4 ra = ld_i4(c + lane), rb = ld_i4(c + 64 + lane);
+                    UeState u = unpack(ra);
+                    const int i = rb.w & 0xFFFFF, sdur = (int)((unsigned)rb.x >> 24);
+                    int tcu = tend;
+                    bool granted = false;
+                    if (u.act == ACT_M1 && u.pre != 0) {
+                        const int gs = granted_at(i, u.pre - 1, max(te - sdur - 1, tlast - 14), tlast);
+                        if (gs >= 0) { granted = true; tcu = gs + 1; }
+                    }
+                    pw_catch_up(u, pw_make(te - sdur, sdur, 0), granted, i, tcu, K.fmA, tab);
+                    st_i4(rec32 + 2 * (size_t)i, pack(u)); st_i4(rec32 + 2 * (size_t)i + 1, make_int4(rb.x & 0xFFFFFF, rb.y, rb.z, (int)PW_IDLE));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
         PRACH_G int *const timers = (PRACH_G int *)PD->timers;
         PRACH_G v4i_t *const logs = (PRACH_G v4i_t *)PD->logs;
         long long sumT = 0;
         int ptcS = 0, fcS = 0;
         unsigned long long ndS = 0;
         for (int i = tid; i < nUE; i += TB) {
-            const BRec R = brec_load(rec32 + 2 * (size_t)i);
-            UeState u = unpack(R.a);
-            const ColdRegs cold = cold_unpack(R.b);
-            if (status == PRACH_OK && tlast >= 0 && u.act != ACT_IDLE)
-                pw_catch_up(u, (unsigned)R.b.w, granted_in(tlast & 1, i), i, tend, K.fmA, tab);
+            const int4 ra = ld_i4(rec32 + 2 * (size_t)i), rb = ld_i4(rec32 + 2 * (size_t)i + 1);
+            const UeState u = unpack(ra);
+            const ColdRegs cold = cold_unpack(rb);
             const int timer = u.act == ACT_IDLE ? -1 : (u.act == ACT_DONE ? u.tb : tend - u.tb);
             if (u.act == ACT_DONE) { sumT += timer; ptcS += cold.ptc; fcS += cold.fcnt; }
-            ndS += (unsigned)R.b.x & 0xFFFFFFu;
+            ndS += (unsigned)rb.x & 0xFFFFFFu;
             timers[i] = u.act == ACT_DONE ? timer : INT_MIN;
             if (logs) {
                 prach_ue_log o;
@@ -867,13 +920,13 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         o->ptcSum = scal[B_PTC]; o->fcSum = scal[B_FC];
         o->nSuccess = scal[B_NSUCC]; o->finalSuccess = scal[B_NSUCC]; o->continueFailed = scal[B_CONTF];
         o->status = status;
-        o->hard_error = why; // (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 a calendar list or the granted list: reported by the engine)
+        o->hard_error = why; // (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 the chunk pool / a chunk table / a join list, 6 the grant notes: reported by the engine)
         o->time_exit = time_exit;
         o->collisionPreambles = scal[B_COLL]; o->totalPreambleTxop = scal[B_TXOP];
         o->activeCheck = activeCheck;
         o->steps = steps;
-        o->visits = (unsigned long long)(unsigned)scal[B_JOINS]; // (join-calendar entries: one per contention window)
-        o->events = (unsigned long long)(unsigned)scal[B_EVENTS];
+        o->visits = (unsigned long long)(unsigned)scal[B_JOINS]; // (join-list entries: one per contention window)
+        o->events = (unsigned long long)(unsigned)scal[B_EVENTS]; // (records streamed through the event body, whole chunks)
 #ifdef PRACH_STAMPS
         for (int k = 0; k < 24; k++) o->fstamps[k] = fstamps[k];
 #endif
@@ -882,10 +935,11 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
 
 size_t batch_kernel_lds_bytes(int waves, bool glibc) { return glibc ? (size_t)BLG::END : waves == 8 ? (size_t)BL<8>::END : (size_t)BL<16>::END; }
 int batch_max_preambles() { return NPB; }
-int batch_max_rar_window() { return 64; }
+int batch_max_rar_window() { return 11; }
 int batch_max_subframes() { return 65000; }
 int batch_max_groups(bool glibc) { return glibc ? BGG : (1 << 14); }
-int batch_max_rar_window_two_per_cu() { return BCap<8>::HRING; }
+int batch_max_rar_window_two_per_cu() { return 11; }
+int batch_chunk_bytes() { return CHUNK * 16; }
 int batch_calendar_slots(int backoff, int accessTime, int maxRarWindow) { // power of two >= the furthest a UE is ever scheduled ahead (+ its window), at most CR
     const int need = backoff + (accessTime > 5 ? accessTime : 5) + maxRarWindow + 70;
     int r = 64;

@@ -82,8 +82,12 @@ struct TrialDev {
     int *sector;                 // PRACH_FLAG_SECTOR_GRANTS: per UE, the sector drawn by activateUEs (WithNOMA:393-410); else null
     // batch kernel (prach_batch.hip) only
     int4 *rec32;                 // [nUE][2] the 32-byte event record
-    int *ecal, *jcal;            // [calmask + 1][calcap] event / join calendar: the UEs whose next event / whose contention window falls into a subframe
-    int calcap, calmask;         // entries per calendar list; calendar slots - 1 (slot = subframe & calmask)
+    int4 *chunks;                // [nchunks][128] the pool of 2 KB chunks: the records of 64 UEs whose next event falls into one subframe
+    int *ctab;                   // [calmask + 1][tcap] chunk table: the chunks of every future subframe's event list
+    int *cpool;                  // [2][nchunks] shared pool of free chunk ids
+    int nchunks, tcap;
+    int *jcal;                   // [calmask + 1][calcap] join lists: the UEs whose contention window opens in a subframe
+    int calcap, calmask;         // entries per join list; calendar slots - 1 (slot = subframe & calmask)
     int *qov;                    // [nUE] early-leaver candidates of a subframe beyond their LDS part
     int2 *evov;                  // [2 nUE] the resolver's event list of a subframe beyond its LDS part
     unsigned long long *diag;    // diagnostic build (PRACH_STAMPS) only: [CLUSTER_MAX_G][32] per-workgroup phase stamps of a cluster trial; else null
@@ -119,6 +123,7 @@ int batch_max_rar_window();
 int batch_max_subframes();
 int batch_max_groups(bool glibc = false);
 int batch_max_rar_window_two_per_cu();
+int batch_chunk_bytes();
 int batch_calendar_slots(int backoff, int accessTime, int maxRarWindow);
 int batch_max_calendar_slots();
 hipError_t launch_batch_kernel(const TrialDev *params, int ntrials, int waves, bool glibc, hipStream_t stream);

@@ -80,8 +80,8 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct TrialLayout {
     size_t rec, ptc, ftt, stt, fcnt, nd, evbuf, evbuf2, sidx, sched, stream, logs, timers, out, mbox, cand;
     size_t n_pre0, n_sector, n_gain, n_lgain, n_nd0, sector;
-    size_t rec32, ecal, jcal, qov, evov; // batch kernel
-    int calcap, calslots;
+    size_t rec32, chunks, ctab, cpool, jcal, qov, evov; // batch kernel
+    int calcap, calslots, npool, tcap;
     size_t diag;                 // diagnostic build: per-workgroup stamps (zeroed region)
     size_t seeds, nchunks; // glibc: one 31-word window per STREAM_CHUNK outputs (device-side generation)
     size_t stream_len, sched_len;
@@ -149,21 +149,24 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         const prach_cfg &c = cfgs[idx[k]];
         TrialLayout &T = L.t[k];
         const size_t n = (size_t)c.nUE;
-        T.rec = T.ptc = T.ftt = T.stt = T.fcnt = T.nd = T.rec32 = T.ecal = T.jcal = T.qov = T.evov = 0;
-        T.calcap = T.calslots = 0;
+        T.rec = T.ptc = T.ftt = T.stt = T.fcnt = T.nd = T.rec32 = T.chunks = T.ctab = T.cpool = T.jcal = T.qov = T.evov = 0;
+        T.calcap = T.calslots = T.npool = T.tcap = 0;
         if (batch) { // prach_batch.hip: 32-byte event records, the two calendars, the global parts of the candidate and event lists
-            // A calendar list holds the UEs scheduled into ONE subframe.  txTime is aligned to the access slots (Beta.c:268-277), so the UEs of a whole
-            // access slot open their windows — and, maxRarWindow - 1 subframes later, have their events — in the SAME subframe: an overloaded trial (more
-            // UEs than its UL grants can serve: every UE cycles through backoff and window about every 17 subframes) puts ~0.3 nUE into one list, a trial
-            // that is not overloaded far less.  A trial that fills a list anyway leaves with PRACH_ERR_INTERNAL and is rerun with lists of nUE entries,
-            // which cannot fill (run_trials_impl).  128 slots x 40 064 entries x 2 calendars = 41 MB for the overloaded 100 000-UE point, 13 MB otherwise.
+            // The records of the UEs under way travel in 2 KB chunks of 64: every UE has one record, so ceil(nUE / 64) full chunks, plus the open chunks of the
+            // wavefronts (at most 64 each), plus what sits in their stacks of free ids (64 each), plus slack: twice the full chunks + 2 112.  A join list holds
+            // the UEs whose window opens in ONE subframe: txTime is aligned to the access slots (Beta.c:268-277), so an overloaded trial (more UEs than its UL
+            // grants can serve: every UE cycles through backoff and window about every 17 subframes) puts ~0.3 nUE into one list, another trial far less.
+            // A trial that exhausts either leaves with PRACH_ERR_INTERNAL and is rerun with a doubled pool and lists of nUE entries (run_trials_impl).
             T.calslots = batch_calendar_slots(c.backoff, c.accessTime, c.maxRarWindow);
             const double steps_ = (double)((c.max_steps > 0 && c.max_steps < prach_max_time(&c)) ? c.max_steps : prach_max_time(&c));
             const bool overloaded = (double)c.nUE > (double)std::max(0, c.nGrantUL - 1) * steps_ / 5.0;
             T.calcap = (int)std::min(n, std::max<size_t>(4096, overloaded ? n * 2 / 5 : n / 8)) + 64;
             if (calendar_cap > 0) T.calcap = (int)calendar_cap;
-            if (full_calendars) T.calcap = (int)n + 64;
-            T.rec32 = take(32 * n); T.ecal = take(4 * (size_t)T.calslots * (size_t)T.calcap); T.jcal = take(4 * (size_t)T.calslots * (size_t)T.calcap);
+            T.npool = 2 * (int)((n + 63) / 64) + 2 * 16 * 64 + 64;
+            if (full_calendars) { T.calcap = (int)n + 64; T.npool *= 2; }
+            T.tcap = (int)((n + 63) / 64) + 256;
+            T.rec32 = take(32 * n); T.chunks = take((size_t)batch_chunk_bytes() * (size_t)T.npool); T.ctab = take(4 * (size_t)T.calslots * (size_t)T.tcap);
+            T.cpool = take(8 * (size_t)T.npool); T.jcal = take(4 * (size_t)T.calslots * (size_t)T.calcap);
             T.qov = take(4 * n); T.evov = take(16 * n);
         } else {
             T.rec = take(16 * n);
@@ -431,7 +434,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         d.dense_pass = e->opt_dense ? 1 : 0;
         d.pipeline = e->opt_pipeline ? 1 : 0;
         if (batch) {
-            d.rec32 = reinterpret_cast<int4 *>(A + L.rec32); d.ecal = reinterpret_cast<int *>(A + L.ecal); d.jcal = reinterpret_cast<int *>(A + L.jcal); d.calcap = L.calcap; d.calmask = L.calslots - 1;
+            d.rec32 = reinterpret_cast<int4 *>(A + L.rec32); d.chunks = reinterpret_cast<int4 *>(A + L.chunks); d.ctab = reinterpret_cast<int *>(A + L.ctab); d.cpool = reinterpret_cast<int *>(A + L.cpool); d.nchunks = L.npool; d.tcap = L.tcap;
+            d.jcal = reinterpret_cast<int *>(A + L.jcal); d.calcap = L.calcap; d.calmask = L.calslots - 1;
             d.qov = reinterpret_cast<int *>(A + L.qov); d.evov = reinterpret_cast<int2 *>(A + L.evov);
         } else {
             d.rec = reinterpret_cast<int4 *>(A + L.rec);
@@ -656,8 +660,8 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         if (std::getenv("PRACH_PRINT_STAMPS")) {
             static const char *const nm[24] = {"head", "phaseB", "S1", "leavers", "S2", "publish", "window-rest", "take1", "S3", "round2", "S4", "calls", "S5", "grants", "S6", "phaseA",
                                                "w:phaseA|A-barrier", "w:loads", "w:refill", "t:buckets", "-", "-", "-", "-"};
-            static const char *const nmb[24] = {"head", "joins", "-", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "b:select", "b:bookkeep", "b:schedule",
-                                                "b:wait-next", "b:stores", "-", "-", "-", "-", "-", "-"}; // prach_batch.hip
+            static const char *const nmb[24] = {"head", "joins", "-", "body", "S1", "leavers", "S2", "classify", "S4", "calls", "S5", "grants", "S6", "-", "-", "-",
+                                                "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_batch.hip
             static const char *const nmn[24] = {"head", "publish+gather", "gather-barrier", "resolve(w0)", "resolve-barrier", "passB+A(w0)", "pass-barrier", "-", "r:to-gains", "r:rank+sort", "r:pairing", "-", "-", "-", "-", "-",
                                                 "-", "-", "-", "-", "-", "-", "-", "-"}; // prach_noma.hip, per SUBFRAME (x accessTime = per slot)
             const char *const *const names = noma ? nmn : e->last.rec_mode == CLUSTER_REC_BATCH ? nmb : nm;
@@ -682,7 +686,7 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
             std::fprintf(stderr, "[prach] lcluster_kernel: trial nUE=%d left at subframe %d with status %d, capacity code %d\n", c.nUE, dr.time_exit, dr.status, dr.hard_error);
         if (batch && dr.status == PRACH_ERR_INTERNAL && dr.hard_error == 5 && !e->full_calendars) e->cal_overflow.push_back(idx[k]);
         if (dr.status == PRACH_ERR_INTERNAL && e->last.rec_mode == CLUSTER_REC_BATCH && std::getenv("PRACH_VERBOSE"))
-            std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d left at subframe %d: capacity %d (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 a calendar list / the granted list)\n", c.nUE, dr.time_exit, dr.hard_error);
+            std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d left at subframe %d: capacity %d (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 the chunk pool / a chunk table / a join list, 6 the grant notes)\n", c.nUE, dr.time_exit, dr.hard_error);
         if (dr.status != PRACH_OK) continue;
         // totalDelay is a FLOAT running sum in index order (Beta.c:186,193): exact in integer
         // arithmetic while it stays below 2^24, otherwise replay the float additions on the host.

@@ -196,7 +196,7 @@ __device__ __forceinline__ UeOut ue_select(UeState &u, const UePlan &pl, const i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// SCHEDULE WORDS (prach_batch.hip): what the event body knows of a UE's future when it lets go of it — one 32-bit word kept in the UE's record:
+// SCHEDULE WORDS (prach_batch.hip): what the event body knows of a UE's future when it lets go of it — one 32-bit word (its window length also rides in the UE's record):
 //     [15:0]  tj   subframe from which the UE is matched by preambleCollision scans (its txTime)               0xFFFF: never
 //     [21:16] dur  number of subframes it then contends with its RAR window open (Beta.c:245): matched in [tj, tj + dur)
 //     [29:24] preamble       [30] finished for good
@@ -230,49 +230,19 @@ __device__ __forceinline__ void pw_catch_up(UeState &u, const unsigned sw, const
     if (sdur > 0 && t > stj) { u.rar += t - stj; if (!granted) u.tx = t; } // (a granted UE counted its window subframes too: Beta.c:245 runs before the call)
 }
 
-// the schedule word of a UE after the event body of subframe t.  retx_next: its next event is certain to be "the RAR window closes, retransmit"
-// (Beta.c:245,282-308) — the commonest event by far, which prach_batch.hip lists apart and runs through ue_window_retx below
-__device__ __forceinline__ unsigned pw_schedule(UeState &u, const int t, const int maxRar, const int maxMsg2, bool &retx_next) {
-    retx_next = false;
+// the schedule word of a UE after the event body of subframe t
+__device__ __forceinline__ unsigned pw_schedule(UeState &u, const int t, const int maxRar) {
     if (u.act == ACT_DONE) return PW_DONE;
     if (u.act == ACT_M3) return u.tx > t ? pw_make(u.tx, 0, 0) : PW_IDLE; // Msg3 / Msg4 at txTime (a txTime in the past never comes: Beta.c:167)
     if (u.pend == PEND_RESET || u.pend == PEND_PASSIVE || u.pend == PEND_RJOIN) return pw_make(t + 1, 0, 0); // outcome needs the caller tables of t
-    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) u.tx = t + 1; // bumped, collided, or singleton without a grant (a grant: the next subframe's event list)
+    if (u.pend == PEND_CALLER || u.pend == PEND_STAY) u.tx = t + 1; // bumped, collided, or singleton without a grant (a grant: noted by the resolver, applied when the record comes up)
     // The clean cases: asleep until txTime (nowBackoff runs out exactly then: every reschedule sets nowBackoff = txTime - time,
     // Beta.c:279,305,399) or contending from the next subframe on (nowBackoff <= 0); from txTime on the UE is matched and counts its
     // RAR window (Beta.c:245) until the window closes.  Anything else (never seen with the reference's parameters) is simply looked
     // at again in the next subframe by the full body.
     const bool clean = u.tx > t && (u.bo > 0 ? u.bo == u.tx : u.tx == t + 1);
     if (!clean) return pw_make(t + 1, 0, u.pre - 1);
-    // (act is ACT_M1 here, with a preamble: at tj + dur the window is closed — rarWindow + 1 >= maxRarWindow — and nowBackoff is 0)
-    retx_next = u.pre != 0 && u.mrc < maxMsg2 && u.rar + 1 <= maxRar;
     return pw_make(u.tx, max(0, maxRar - 1 - u.rar), u.pre - 1);
-}
-
-// ---- "the RAR window closes, retransmit" for a UE scheduled with retx_next (not granted since): pw_catch_up + ue_plan + ue_select on the one path such
-// a UE takes — Beta.c:245 (the window's last subframe), :282-308 (retransmission with a uniform backoff, aligned to the access slots).  ok: the record is
-// in the state pw_schedule promised (checked, so that a wrong promise is a reported error, never a wrong result).  d1: the UE's next draw.
-template <class COLD>
-__device__ __forceinline__ UeOut ue_window_retx(UeState &u, const unsigned sw, const int d1, const int i, const int t, const UeK &K, COLD &cold, bool &ok) {
-    const int stj = (int)(sw & 0xFFFFu), sdur = (int)((sw >> 16) & 0x3Fu);
-    ok = u.act == ACT_M1 && u.pre != 0 && (u.pend == PEND_NONE || u.pend == PEND_CALLER || u.pend == PEND_STAY) && t == stj + sdur;
-    u.pend = PEND_NONE;
-    if (sdur > 0) { u.rar += sdur; u.tx = t; } // matched, bumped and counted in every subframe of [tj, tj + dur)
-    ok = ok && now_backoff(u.bo, t) <= 0 && u.rar + 1 >= K.maxRar && u.mrc < K.maxMsg2;
-    UeOut o;
-    o.evtype = UEV_NONE; o.evp = 0; o.evq = 0;
-    o.oldp = u.pre - 1;
-    o.member_pre = u.tx == t;
-    o.eclass = false; o.passive = false; o.dirty = true;
-    u.rar = 0; u.mrc++; // Beta.c:245 then :282-285
-    cold.ptc_inc(i);
-    const int tmp = fastmod(d1, K.fmB);
-    u.tx = slot_align_fm(t + tmp, K.fmA);
-    u.bo = enc_backoff(u.tx - t, t);
-    cold.stt_set(i, u.tx);
-    if (u.tx == t) { u.pend = PEND_CALLER; o.evtype = UEV_CALLER; o.evp = o.oldp; } // the "late joiner"
-    else if (o.member_pre) o.eclass = true;
-    return o;
 }
 
 // resolver-side info word of a special event (20 bits): type[2:0] ispre[3] bucket p[11:4] old bucket q[19:12]
