@@ -567,24 +567,13 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
     else if (batch) {
         e->last.rec_mode = CLUSTER_REC_BATCH;
         e->last.xcd_packed = 0;
-        // Workgroup shape (speed only, same results): two 512-thread workgroups = two trials per CU hide each other's barriers and event
-        // record latencies (1000 Beta.c trials: 310 vs 374 ms) — unless the trials are overloaded (more UEs than the UL grants of the
-        // whole trial can serve: an event-dense body, where one 1024-thread workgroup per CU measured 3-7 % faster: 827 vs 854 ms on
-        // config 3), or there are too few trials to fill the CUs twice.
+        // Workgroup shape (speed only, same results).  A launch is as long as its longest trial alone or as its work needs, whichever is more: a 100 000-UE
+        // trial runs 176 ms on 16 wavefronts and 228 ms on 8, so while the trials do not fill the CUs twice the 1024-thread shape wins (510 sweep trials:
+        // 193 / 370 ms — Beta.c / WithNOMA — against 235 / 419 ms); from there on two 512-thread workgroups = two trials per CU hide each other's
+        // barriers (1000 trials: 248 / 594 ms against 354 / 709 ms; 2000: 473 / 1 105 against 690 / 1 366): scripts/gpu_shape_probe.sh.
         int waves = (int)e->opt_batch_waves;
         if (rng_mode == PRACH_RNG_GLIBC) waves = 16;
-        if (waves == 0) {
-            double upd_all = 0, upd_over = 0;
-            for (int k = 0; k < m; k++) {
-                const prach_cfg &c = cfgs[idx[k]];
-                const double steps = (double)td[k].stop, capacity = (double)std::max(0, c.nGrantUL - 1) * steps / 5.0;
-                upd_all += (double)c.nUE * steps;
-                if ((double)c.nUE > capacity) upd_over += (double)c.nUE * steps;
-            }
-            waves = (m >= 3 * e->num_cus && upd_over < 0.5 * upd_all) ? 8 : 16;
-        }
-        for (int k = 0; k < m; k++) // (the 512-thread shape keeps a 16-subframe histogram ring)
-            if (cfgs[idx[k]].maxRarWindow > batch_max_rar_window_two_per_cu()) waves = 16;
+        if (waves == 0) waves = m >= 3 * e->num_cus ? 8 : 16;
         e->last.workgroups = m;
         HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, waves, rng_mode == PRACH_RNG_GLIBC, e->stream));
     }

@@ -46,16 +46,18 @@ ALGO_BYTES_PER_UPDATE = 32.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 KERNEL_NAMES = {0: "prach::cluster_kernel (records in global memory)", 1: "prach::cluster_kernel (8+4 B records, one workgroup per trial)",
                 2: "prach::cluster_kernel (LDS-resident records)", 3: "prach::lcluster_kernel (LDS-resident UE state)",
-                4: "prach::batch_kernel (one workgroup per trial: 4-byte pass words + 32-byte event records)"}
+                4: "prach::batch_kernel (one workgroup per trial: the 32-byte records travel with the events, in 2 KB chunks)"}
 
 
 def own_bytes(tm):
     """The bytes the one-workgroup-per-trial kernel itself asks for, from its own counters (prach_timing.group_visits / .event_ues).
-    batch_kernel: a 64-UE group visit reads one 4-byte pass word per lane; an event UE reads and writes one 32-byte record, writes its
-    pass word and passes through the event queue (4 B in, 4 B out): 76 B.  The general kernel's 8 + 4 byte form: 8 B per lane and
-    visit, ~40 B per event."""
-    vis, ev = (256, 76) if tm.rec_mode == 4 else (512, 40)
-    return tm.group_visits * vis + tm.event_ues * ev
+    batch_kernel (round 4: the state travels with the event): an event UE's 32-byte record is read from the chunk of the subframe's event
+    list it sits in and written into the chunk of the subframe of its next event (whole chunks are read: event_ues counts 64 per chunk),
+    64 B; a contention window costs one 4-byte join-list entry written and one read (group_visits counts the joins), 8 B.  The general
+    kernel's 8 + 4 byte form: 8 B per lane and 64-UE visit, ~40 B per event."""
+    if tm.rec_mode == 4:
+        return tm.event_ues * 64 + tm.group_visits * 8
+    return tm.group_visits * 512 + tm.event_ues * 40
 
 
 def cpu_reference_baseline(budget_s: float):
@@ -380,8 +382,8 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
         # own_bytes()) and the dense-formulation rate is carried beside it, labelled.
         "roofline": {"bound": "hbm", "achieved": sum(owns) / (sum(kmss) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": sum(owns) / (sum(kmss) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "prach::batch_kernel (4-byte pass words + 32-byte event records, one workgroup per trial)", "kernel_ms_rank0": sum(kmss) / args.steps,
-                     "bytes": "the kernel's own bytes: 256 B per 64-UE group visit + 76 B per event UE (prach_timing.group_visits / .event_ues), rank 0",
+                     "traffic": None, "kernel": "prach::batch_kernel (event lists of 32-byte records in 2 KB chunks, one workgroup per trial)", "kernel_ms_rank0": sum(kmss) / args.steps,
+                     "bytes": "the kernel's own bytes: 64 B per event UE (its 32-byte record streamed in and out, whole 64-record chunks) + 8 B per contention window (join-list entry), rank 0",
                      "own_bytes_per_update": sum(owns) / max(1, updates_per_step * args.steps / world),
                      "dense_formulation_GBps_32B_per_update": ALGO_BYTES_PER_UPDATE * updates_per_step / world / (sum(kmss) / args.steps * 1e-3) / 1e9,
                      "note": "counter-measured HBM traffic of this regime (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes): profiles/r03_config3.md "

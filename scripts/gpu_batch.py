@@ -22,8 +22,7 @@ digest = 0
 for r in res:
     digest = zlib.crc32(bytes(r), digest)
 print(f"digest={digest:08x} trials={len(cfgs)} variant={variant} G={G} launches={tm.launches} wgs={tm.workgroups} kernel={tm.kernel_ms:.1f}ms wall={wall:.2f}s updates={upd:.3e} kernel_upd/s={upd/(tm.kernel_ms*1e-3):.3e} algoGB/s={32*upd/(tm.kernel_ms*1e-3)/1e9:.0f} bad={sum(r.status!=0 for r in res)}")
-# the kernel's OWN bytes.  batch_kernel (rec_mode 4): a visit reads one 4-byte pass word per lane; an event UE reads and writes one 32-byte
-# record, writes its pass word and passes through the queue (4 B in, 4 B out).  The general kernel's 8 + 4 byte form: 8 B per lane and visit, ~40 B per event.
-vis_b, ev_b = (256, 76) if tm.rec_mode == 4 else (512, 40)
-own = tm.group_visits * vis_b + tm.event_ues * ev_b
-print(f"rec_mode={tm.rec_mode} fallback={tm.fallback_trials} own traffic: {tm.group_visits:.3e} group visits x {vis_b} B, {tm.event_ues:.3e} event UEs x {ev_b} B -> {own/1e9:.1f} GB = {own/upd:.2f} B/update = {own/(tm.kernel_ms*1e-3)/1e12:.2f} TB/s")
+# the kernel's OWN bytes.  batch_kernel (rec_mode 4): an event UE's 32-byte record is read from the chunk it sits in and written into the chunk of its next event's
+# subframe (whole 64-record chunks are counted), 64 B; a contention window costs a 4-byte join-list entry out and in, 8 B.  The general kernel's 8 + 4 byte form: 8 B per lane and visit, ~40 B per event.
+own = tm.event_ues * 64 + tm.group_visits * 8 if tm.rec_mode == 4 else tm.group_visits * 512 + tm.event_ues * 40
+print(f"rec_mode={tm.rec_mode} fallback={tm.fallback_trials} own traffic: {tm.event_ues:.3e} event records x 64 B, {tm.group_visits:.3e} {'joins x 8 B' if tm.rec_mode == 4 else 'group visits x 512 B'} -> {own/1e9:.1f} GB = {own/upd:.2f} B/update = {own/(tm.kernel_ms*1e-3)/1e12:.2f} TB/s")

@@ -363,7 +363,9 @@ def test_cluster_capacity_fallback_is_exact(pkg, ob, engine):
     cfg = pkg.make_cfg(60000, variant=1, rng_mode=pkg.RNG_PHILOX, seed=2, **kw)
     (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
     tm = engine.timing()
-    assert tm.launches >= 2 and tm.fallback_trials == 1  # cluster attempt + exact rerun (on the batch kernel first, on trial_kernel if that overflows too)
+    # cluster attempt + exact rerun on the batch kernel — whose join lists (every UE of the trial opens its window in the same subframe here) fill too: once more with
+    # full-size lists; every rerun is counted and reported
+    assert tm.launches >= 2 and 1 <= tm.fallback_trials <= 3
     ores, oues = ob.run_trial(ob.make_cfg(60000, variant=1, **kw), ob.Rng(ob.RNG_PHILOX, 2))
     assert_same(pkg, res, logs, ores, oues, "fallback")
 
