@@ -89,6 +89,8 @@ def lib():
         L.prach_cfg_defaults.restype = None
         L.prach_cfg_validate.argtypes = [C.POINTER(PrachCfg)]
         L.prach_max_time.argtypes = [C.POINTER(PrachCfg)]
+        L.prach_trial_cost.argtypes = [C.POINTER(PrachCfg)]
+        L.prach_trial_cost.restype = C.c_double
         L.prach_arrival_schedule.argtypes = [C.POINTER(PrachCfg), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32)]
         L.prach_glibc_stream.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
         L.prach_glibc_stream.restype = None
@@ -116,7 +118,7 @@ def lib():
 
 
 EXPORTS = ("prach_engine_create", "prach_engine_destroy", "prach_engine_set", "prach_run_trials", "prach_last_timing",
-           "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_arrival_schedule", "prach_glibc_stream",
+           "prach_cfg_defaults", "prach_cfg_validate", "prach_max_time", "prach_trial_cost", "prach_arrival_schedule", "prach_glibc_stream",
            "prach_strerror", "prach_format_logs", "prach_format_results", "prach_format_stdout",
            "prach_result_file_name", "prach_write_trial_files", "prach_noma_activation_table", "prach_format_noma_line",
            "prach_results_csv_accumulate", "prach_results_csv_row", "prach_device_glibc_stream", "prach_noma_activation_range", "prach_noma_activation_stream",

@@ -269,7 +269,7 @@ int main(int argc, char *argv[]) {
         fflush(stdout);
     }
 
-    /* deal the trials to the workers: longest first onto the least loaded (cost = nUE x subframes); glibc mode deals whole seeds */
+    /* deal the trials to the workers: longest first onto the least loaded (cost = prach_trial_cost, a measured table); glibc mode deals whole seeds */
     if (devlist) {
         gpus = 0;
         for (const char *q = devlist; *q && gpus < 64;) {
@@ -302,7 +302,7 @@ int main(int argc, char *argv[]) {
                 int best = 0;
                 for (int w = 1; w < gpus; w++) if (wload[w] < wload[best]) best = w;
                 widx[best][wn[best]++] = s_ * npts + k;
-                wload[best] += (double)cfgs[s_ * npts + k].nUE * (double)prach_max_time(&cfgs[s_ * npts + k]);
+                wload[best] += prach_trial_cost(&cfgs[s_ * npts + k]);
             }
     }
 

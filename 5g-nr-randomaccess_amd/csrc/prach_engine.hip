@@ -62,6 +62,7 @@ struct prach_engine {
     int64_t opt_batch = 1;         // 0: one-workgroup-per-trial Philox launches run on the general kernel instead of prach_batch.hip
     int64_t opt_batch_waves = 0;   // wavefronts per batch-kernel workgroup: 8 (512 threads, two trials per CU), 16 (one), 0 = chosen per launch
     int64_t opt_plain_arena = 0;   // 1: the arena is one hipMalloc allocation, re-allocated when it grows (diagnostic)
+    int64_t opt_vmm_fail_after = 0; // test hook: the reserved-range arena cannot map a further piece once it has this many (0: no limit)
     int64_t opt_noma_host_activation = 0; // 1: NOMA.c's activeUE table is built on the host (the reference's libm) instead of by noma_activation_kernel
     int64_t opt_noma_ambiguity_test = 0;  // test hook: the resolver reports every gain sort as ambiguous (exercises the rerun with the host-built table)
     bool force_host_act = false;   // (set for the rerun of trials whose device-built table left a gain comparison inside the error band)
@@ -215,21 +216,34 @@ static bool grow_vmm_arena(prach_engine *e, size_t need) {
         const size_t reserve = align_up(total_b, gran); // (address space, not memory)
         void *p = nullptr;
         if (hipMemAddressReserve(&p, reserve, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); e->vmm = -1; return false; }
-        e->arena = static_cast<char *>(p); e->arena_cap = 0; e->vmm_reserved = reserve; e->vmm_gran = gran; e->vmm = 1;
+        e->arena = static_cast<char *>(p); e->arena_cap = 0; e->vmm_reserved = reserve; e->vmm_gran = std::max(gran, (size_t)2 << 20); e->vmm = 1; // (pieces in multiples of 2 MB whatever the runtime recommends)
     }
     if (need > e->vmm_reserved) return false;
-    // at least a quarter more than what is mapped, at least 256 MB: a sweep's growing calls map a handful of pieces in all
+    // at least a quarter more than what is mapped, at least 256 MB: a sweep's growing calls map a handful of increments in all — each increment in pieces of
+    // at most 1 GB (hipMemSetAccess refused pieces of 2 GB and more: hipErrorInvalidValue)
     size_t delta = align_up(std::max(need - e->arena_cap, std::max(e->arena_cap >> 2, (size_t)256 << 20)), e->vmm_gran);
     delta = std::min(delta, e->vmm_reserved - e->arena_cap);
-    hipMemGenericAllocationHandle_t h;
-    if (hipMemCreate(&h, delta, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemMap(e->arena + e->arena_cap, delta, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
-    hipMemAccessDesc acc{};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(e->arena + e->arena_cap, delta, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap(e->arena + e->arena_cap, delta); (void)hipMemRelease(h); return false; }
-    e->vmm_parts.push_back({h, delta});
-    e->arena_cap += delta;
+    const size_t piece_max = align_up((size_t)1 << 30, e->vmm_gran); // (hipMemSetAccess refuses a piece of 2^31 bytes: hipErrorInvalidValue)
+    while (delta > 0) {
+        const size_t piece = std::min(delta, piece_max);
+        if (e->opt_vmm_fail_after > 0 && (int64_t)e->vmm_parts.size() >= e->opt_vmm_fail_after) return false; // (test hook: as if the device had no more memory to map)
+        hipMemGenericAllocationHandle_t h;
+        auto why = [&](const char *what, hipError_t rc) { if (std::getenv("PRACH_VERBOSE")) std::fprintf(stderr, "[prach] %s of a %zu-byte piece at offset %zu: %s\n", what, piece, e->arena_cap, hipGetErrorName(rc)); (void)hipGetLastError(); };
+        hipError_t rc = hipMemCreate(&h, piece, &prop, 0);
+        if (rc != hipSuccess) { why("hipMemCreate", rc); return false; }
+        rc = hipMemMap(e->arena + e->arena_cap, piece, 0, h, 0);
+        if (rc != hipSuccess) { why("hipMemMap", rc); (void)hipMemRelease(h); return false; }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        // (access is set for the whole mapped range from the base: inside this engine the runtime refuses the new piece alone — hipErrorInvalidValue for every
+        //  piece behind the first, of any size — although profiles/tools/vmm_probe.hip, the same calls in a bare program, is granted it)
+        rc = hipMemSetAccess(e->arena, e->arena_cap + piece, &acc, 1);
+        if (rc != hipSuccess) { why("hipMemSetAccess", rc); (void)hipMemUnmap(e->arena + e->arena_cap, piece); (void)hipMemRelease(h); return false; }
+        e->vmm_parts.push_back({h, piece});
+        e->arena_cap += piece; // (pieces mapped before a failure stay: the caller sees the arena short of `need` and falls back)
+        delta -= piece;
+    }
     return true;
 }
 static void free_arena(prach_engine *e) {
@@ -1027,6 +1041,7 @@ int prach_engine_set(prach_engine *e, const char *key, int64_t value) {
     if (std::strcmp(key, "lds_records") == 0) { e->opt_lds_records = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "fast") == 0) { e->opt_fast = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "batch") == 0) { e->opt_batch = value != 0; return PRACH_OK; }
+    if (std::strcmp(key, "vmm_fail_after") == 0) { if (value < 0) return PRACH_ERR_ARG; e->opt_vmm_fail_after = value; return PRACH_OK; }
     if (std::strcmp(key, "plain_arena") == 0) { if (e->arena_cap) return PRACH_ERR_ARG; e->opt_plain_arena = value != 0; return PRACH_OK; } // (before the first call only)
     if (std::strcmp(key, "noma_ambiguity_test") == 0) { e->opt_noma_ambiguity_test = value != 0; return PRACH_OK; }
     if (std::strcmp(key, "noma_host_activation") == 0) { e->opt_noma_host_activation = value != 0; return PRACH_OK; }

@@ -63,6 +63,29 @@ int prach_cfg_validate(const prach_cfg *c) {
 
 int prach_max_time(const prach_cfg *c) { return c->uniform ? 60000 : 10000; } /* Beta.c:92,103 */
 
+/* What a trial costs inside a batched launch, in kernel microseconds: the unit the multi-GPU dealing balances (dist.py shard_trials, prach_sim --gpus).
+   Measured on an MI355X, 1024 trials of one size per call (scripts/gpu_cost_table.py -> profiles/r04_cost_table.json): the Beta.c program as committed (54 UL
+   grants: every UE is served, cost grows with the contention of the big points) and RandomAccessWithNOMA's defaults (12 grants: overloaded from 20 000 UEs
+   on, linear in nUE); linear between the sweep's points, proportional beyond them, scaled by the subframes a shortened trial runs.  Uniform arrivals
+   (60 000 subframes, a handful of live UEs each) and NOMA.c are costed by size alone: their sweeps deal evenly whatever the constant. */
+double prach_trial_cost(const prach_cfg *c) {
+    static const double beta_us[10] = {54.99, 89.81, 106.65, 121.23, 140.4, 190.78, 274.89, 369.38, 476.71, 589.0};
+    static const double over_us[10] = {59.74, 173.61, 280.2, 385.12, 493.9, 604.92, 717.54, 827.28, 935.91, 1044.71};
+    const double n = (double)c->nUE;
+    const int maxt = prach_max_time(c);
+    const double frac = (c->max_steps > 0 && c->max_steps < maxt) ? (double)c->max_steps / (double)maxt : 1.0;
+    if (c->variant == PRACH_VARIANT_NOMA_C) return 2.0e-3 * n * frac;
+    if (c->uniform) return 1.2e-3 * n * frac;
+    /* overloaded: more UEs than the UL grants of the whole trial can serve (nGrantUL - 1 per 5 ms window, Beta.c:112,336) */
+    const double capacity = (double)(c->nGrantUL > 1 ? c->nGrantUL - 1 : 0) * (double)maxt / 5.0;
+    const double *tab = (c->variant == PRACH_VARIANT_WITHNOMA_C || n > capacity) ? over_us : beta_us;
+    double x = n / 10000.0 - 1.0; /* position in the table: 0 at nUE = 10 000 */
+    if (x <= 0.0) return tab[0] * n / 10000.0 * frac;
+    if (x >= 9.0) return tab[9] * n / 100000.0 * frac;
+    const int k = (int)x;
+    return (tab[k] + (tab[k + 1] - tab[k]) * (x - (double)k)) * frac;
+}
+
 const char *prach_strerror(int s) {
     switch (s) {
     case PRACH_OK: return "ok";

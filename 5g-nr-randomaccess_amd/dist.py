@@ -16,8 +16,12 @@ AGG_FIELDS = ("trials", "nSuccessUE", "preambleTxCount", "sumTimer", "collisionP
               "continueFaliedUEs", "finalSuccessUEs", "steps", "updates")
 
 
-def trial_cost(cfg) -> int:
-    return int(cfg.nUE) * (60000 if cfg.uniform else 10000)
+def trial_cost(cfg) -> float:
+    """Kernel microseconds of this trial inside a batched launch: the library's measured table (prach_trial_cost, csrc/prach_host.c;
+    scripts/gpu_cost_table.py) — the same weights `prach_sim --gpus N` deals with."""
+    import ctypes
+    from . import lib
+    return float(lib().prach_trial_cost(ctypes.byref(cfg)))
 
 
 def shard_trials(cfgs, rank: int, world: int, chain_by_seed: bool = False):
@@ -31,9 +35,9 @@ def shard_trials(cfgs, rank: int, world: int, chain_by_seed: bool = False):
         units = [[i for i in range(n) if int(cfgs[i].seed) == s] for s in seeds]
     else:
         units = [[i] for i in range(n)]
-    cost = [sum(trial_cost(cfgs[i]) for i in u) for u in units]
+    cost = [sum(trial_cost(cfgs[i]) for i in u) for u in units]  # (floats from one C function: identical on every rank)
     order = sorted(range(len(units)), key=lambda k: (-cost[k], k))
-    load = [0] * world
+    load = [0.0] * world
     mine = []
     for k in order:
         r = min(range(world), key=lambda q: (load[q], q))

@@ -163,6 +163,9 @@ int prach_engine_set(prach_engine *, const char *key, int64_t value);
 void prach_cfg_defaults(prach_cfg *cfg, int variant); /* Beta.c:47-57 / WithNOMA:70-88 */
 int prach_cfg_validate(const prach_cfg *cfg);
 int prach_max_time(const prach_cfg *cfg);
+/* What this trial costs inside a batched launch, in kernel microseconds on an MI355X (a measured table, prach_host.c): the weight the multi-GPU dealing of the
+   --times x sweep grid balances — the reference runs that grid serially (RandomAccessWithNOMA.c:216-221), so there is nothing there to replace. */
+double prach_trial_cost(const prach_cfg *cfg);
 /* out[s] = activeCheck after the arrival update of access slot s (Beta.c:121-134); returns #slots */
 int prach_arrival_schedule(const prach_cfg *cfg, int32_t *out, int cap, int32_t *nAccessUE);
 /* k-th .. k+n-th values of srand(seed)/rand() */

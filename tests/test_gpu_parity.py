@@ -655,6 +655,65 @@ def test_bench_grid_two_ranks_plain_launch(pkg, ob):
     _check_grid_line(pkg, ob, out, 2)
 
 
+def test_engine_arena_growth_paths(pkg, ob, capfd):
+    """The engine's device arena (prach_engine.hip ensure_arena): one reserved virtual range that physical memory is mapped into in pieces as calls grow —
+    over a small -> large -> small -> larger sequence of calls; the same with `plain_arena` (one hipMalloc allocation, re-allocated when it grows); and with
+    the test hook `vmm_fail_after` = 1, which lets the range map ONE piece and then refuses (as a device out of mappable memory would): the engine says so on
+    stderr — once — and carries on with a plain allocation.  Results are the same byte for byte in all three, and the oracle's where checked."""
+    def seq(eng):
+        out = []
+        for ntr, nue, steps in ((3, 3000, 0), (300, 20000, 1500), (2, 3000, 0), (400, 20000, 1500)):
+            cfgs = [pkg.make_cfg(nue, variant=s % 2, rng_mode=pkg.RNG_PHILOX, seed=s, max_steps=steps) for s in range(ntr)]
+            res, _ = eng.run_trials(cfgs)
+            assert all(r.status == 0 for r in res)
+            out.append([bytes(r) for r in res])
+        return out
+    want = None
+    for opts in ({}, {"plain_arena": 1}, {"vmm_fail_after": 1}):
+        eng = pkg.Engine(0)
+        for k, v in opts.items():
+            eng.set(k, v)
+        capfd.readouterr()
+        got = seq(eng)
+        err = capfd.readouterr().err
+        eng.close()
+        assert err.count("falling back to hipMalloc") == (1 if "vmm_fail_after" in opts else 0), (opts, err[-500:])
+        if want is None:
+            want = got
+        assert got == want, opts
+    ores, _ = ob.run_trial(ob.make_cfg(20000, variant=1, max_steps=1500), ob.Rng(ob.RNG_PHILOX, 299), want_ues=False)
+    r = pkg.PrachResult.from_buffer_copy(want[1][299])
+    assert (r.nSuccessUE, r.collisionPreambles, r.totalPreambleTxop, r.sumTimer, r.draws) == (ores.nSuccessUE, ores.collisionPreambles, ores.totalPreambleTxop, ores.sumTimer, ores.draws)
+
+
+def test_bench_grid_four_ranks_on_one_device(pkg, ob):
+    """The widest rehearsal a one-GPU box admits (its process guard allows six processes with the card open: this test process, bench.py's launcher and four
+    ranks — five ranks were killed by it): a plain `python bench.py --gpus 4 --same-device --backend gloo` — four engines alive on one device, each with its
+    own whole-memory address reservation for its arena, thirty trials dealt by the measured cost table — gives n_gpus = 4 and the oracle's aggregates and
+    results.csv.  (World 8 itself: the gloo test of tests/test_dist_cpu.py on the CPU, and the driver's scaling run on the 8-GPU node.)"""
+    out = _run_bench_plain(4, "gloo", ["--same-device"])
+    assert out["config"]["collective_backend"] == "gloo" and len(out["per_rank_sim_seconds"]) == 4
+    _check_grid_line(pkg, ob, out, 4)
+
+
+def test_cli_four_workers_on_one_device(pkg, tmp_path):
+    """`prach_sim --devices 0,0,0,0`: four forked workers on one device against the one-worker run — stdout, files and results.csv identical."""
+    outs = {}
+    for tag, extra in (("one", []), ("four", ["--devices", "0,0,0,0"])):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / "BasicBetaSimulationResults").mkdir()
+        p = subprocess.run([pkg.CLI_PATH, "--program", "beta", "--rng", "philox", "--times", "4", "--sweep", "3000:9000:3000", "--out", str(d),
+                            "--logs", "1", "--csv", str(d / "results.csv")] + extra, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        files = {f.name: f.read_bytes() for f in sorted((d / "BasicBetaSimulationResults").iterdir())}
+        files = {k: (b"\n".join(v.split(b"\n")[:5]) if k.endswith("_Results.txt") else v) for k, v in files.items()}
+        so = "\n".join(l for l in p.stdout.split("\n") if not l.startswith("Latency:"))
+        csv5 = [row.split(b",")[:5] for row in (d / "results.csv").read_bytes().split(b"\r\n")]
+        outs[tag] = (so, files, csv5)
+    assert outs["one"] == outs["four"]
+
+
 def test_bench_grid_two_ranks_rccl(pkg, ob):
     """The same over RCCL (backend nccl: all_reduce on device tensors + gather_object), one rank per GPU — needs two devices."""
     import torch
