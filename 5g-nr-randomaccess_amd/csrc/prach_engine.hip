@@ -199,8 +199,9 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
 //  turns out too small is the ordinary PRACH_ERR_STREAM retry, four times larger)
 uint64_t stream_budget(const prach_cfg &c, int attempt, int64_t factor, double seen) {
     uint64_t per = factor > 0 ? (uint64_t)factor : seen > 0 ? (uint64_t)std::min(450.0, std::max(64.0, 3.0 * seen + 32.0)) : 450; // 100k UEs / 12 grants / backoff 20 consume ~325 per UE
+    if (attempt > 0 && factor <= 0) per = 450; // (a window sized from a light previous call was too small: straight to the default, then four times larger per retry)
     uint64_t b = (uint64_t)c.nUE * per + (1u << 20);
-    return b << (2 * attempt);
+    return b << (2 * std::max(0, attempt - (seen > 0 && factor <= 0 ? 1 : 0)));
 }
 
 // grows the reserved-range arena to at least `need` mapped bytes; false: the mechanism is not available here (nothing has been changed)
@@ -367,6 +368,7 @@ static bool batch_eligible(const prach_engine *e, const prach_cfg &c) {
 // device math library's error band of a rounding / comparison boundary (~1e-6 of them) are recomputed with the host's libm
 // (prach_noma_activation_range) and patched in.  dparams: the launch's TrialDev blocks (device), tabs[k]: trial k's table arrays (device).
 struct ActTab { char *pre0, *sec, *gain, *lgain, *nd0; };
+constexpr int NOMA_ACT_OVERFLOW_RC = -1099; // (internal) noma_activation_kernel flagged more UEs than its list holds
 static int noma_device_activation(prach_engine *e, const TrialDev *dparams, const prach_cfg *cfgs, const int *idx, int m, const std::vector<ActTab> &tabs,
                                   unsigned *dflags, std::vector<std::pair<int, int>> *flagged) {
     int maxUE = 0;
@@ -375,29 +377,32 @@ static int noma_device_activation(prach_engine *e, const TrialDev *dparams, cons
     unsigned nflag = 0;
     HIPCHK(hipMemcpyAsync(&nflag, dflags, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (nflag > (unsigned)NOMA_ACT_FLAG_CAP) {
-        std::fprintf(stderr, "[prach] noma_activation_kernel flagged %u UEs (more than its list holds)\n", nflag);
-        return PRACH_ERR_INTERNAL;
+    if (nflag > (unsigned)NOMA_ACT_FLAG_CAP) { // (e.g. a cell radius just above the 35 m exclusion zone: the redraw loop's iteration limit flags every tenth UE)
+        std::fprintf(stderr, "[prach] noma_activation_kernel flagged %u UEs (more than its list holds): the activation table of this launch is built on the host\n", nflag);
+        return NOMA_ACT_OVERFLOW_RC;
     }
     if (!nflag) return PRACH_OK;
     std::vector<unsigned> fl(2 * (size_t)nflag);
-    HIPCHK(hipMemcpy(fl.data(), dflags + 2, 8 * (size_t)nflag, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(fl.data(), dflags + 2, 8 * (size_t)nflag, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    // the recomputed values are staged in buffers that live until the copies have completed ON THE ENGINE'S STREAM (the simulation kernel is launched on that
+    // stream, which is non-blocking: a copy on the null stream would not be ordered in front of it)
+    struct Patch { int32_t pre0, sec; double gn, lg; uint32_t nd0; };
+    std::vector<Patch> pt(nflag);
     for (unsigned q = 0; q < nflag; q++) {
         const int k = (int)fl[2 * q], i = (int)fl[2 * q + 1];
         if (k < 0 || k >= m || i < 0 || i >= cfgs[idx[k]].nUE) return PRACH_ERR_INTERNAL;
-        int32_t pre0, sec;
-        double gn, lg;
-        uint32_t nd0;
-        const int arc = prach_noma_activation_range(&cfgs[idx[k]], i, i + 1, &pre0, &sec, &gn, &lg, &nd0);
+        const int arc = prach_noma_activation_range(&cfgs[idx[k]], i, i + 1, &pt[q].pre0, &pt[q].sec, &pt[q].gn, &pt[q].lg, &pt[q].nd0);
         if (arc != PRACH_OK) return arc;
         const ActTab &T = tabs[k];
-        HIPCHK(hipMemcpy(T.pre0 + 4 * (size_t)i, &pre0, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(T.sec + 4 * (size_t)i, &sec, 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(T.gain + 8 * (size_t)i, &gn, 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(T.lgain + 8 * (size_t)i, &lg, 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(T.nd0 + 4 * (size_t)i, &nd0, 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(T.pre0 + 4 * (size_t)i, &pt[q].pre0, 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(T.sec + 4 * (size_t)i, &pt[q].sec, 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(T.gain + 8 * (size_t)i, &pt[q].gn, 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(T.lgain + 8 * (size_t)i, &pt[q].lg, 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(T.nd0 + 4 * (size_t)i, &pt[q].nd0, 4, hipMemcpyHostToDevice, e->stream));
         if (flagged) flagged->push_back({k, i});
     }
+    HIPCHK(hipStreamSynchronize(e->stream));
     e->noma_flagged += (int)nflag;
     return PRACH_OK;
 }
@@ -571,6 +576,12 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         std::vector<ActTab> tabs(m);
         for (int k = 0; k < m; k++) tabs[k] = {A + LL.t[k].n_pre0, A + LL.t[k].n_sector, A + LL.t[k].n_gain, A + LL.t[k].n_lgain, A + LL.t[k].n_nd0};
         int rc = noma_device_activation(e, reinterpret_cast<const TrialDev *>(A), cfgs, idx, m, tabs, reinterpret_cast<unsigned *>(A + LL.act_flags), nullptr);
+        if (rc == NOMA_ACT_OVERFLOW_RC && !e->force_host_act) { // the same launch once more with the host-built table (the path a NOMA_AMBIGUOUS rerun takes)
+            e->force_host_act = true;
+            rc = run_group(e, cfgs, idx, m, results, ue_logs, attempt, G, kernel_ms, upload_ms);
+            e->force_host_act = false;
+            return rc;
+        }
         if (rc != PRACH_OK) return rc;
     }
     if (noma) {
@@ -1089,13 +1100,14 @@ static int activation_table_device_impl(prach_engine *e, const prach_cfg *cfg, i
     d.n_pre0 = reinterpret_cast<const int *>(A + opre); d.n_sector = reinterpret_cast<const int *>(A + osec);
     d.n_gain = reinterpret_cast<const double *>(A + ogain); d.n_lgain = reinterpret_cast<const double *>(A + olg);
     d.n_nd0 = reinterpret_cast<const unsigned *>(A + ond);
-    HIPCHK(hipMemcpy(A, &d, sizeof(d), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(A + oflags, 0, 8));
+    HIPCHK(hipMemcpyAsync(A, &d, sizeof(d), hipMemcpyHostToDevice, e->stream)); // (on the engine's stream, like the kernel behind them)
+    HIPCHK(hipMemsetAsync(A + oflags, 0, 8, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     const int idx0 = 0;
     std::vector<ActTab> tabs(1, ActTab{A + opre, A + osec, A + ogain, A + olg, A + ond});
     std::vector<std::pair<int, int>> fl;
     e->noma_flagged = 0;
-    { int rc = noma_device_activation(e, reinterpret_cast<const TrialDev *>(A), cfg, &idx0, 1, tabs, reinterpret_cast<unsigned *>(A + oflags), &fl); if (rc != PRACH_OK) return rc; }
+    { int rc = noma_device_activation(e, reinterpret_cast<const TrialDev *>(A), cfg, &idx0, 1, tabs, reinterpret_cast<unsigned *>(A + oflags), &fl); if (rc != PRACH_OK) return rc == NOMA_ACT_OVERFLOW_RC ? PRACH_ERR_INTERNAL : rc; }
     HIPCHK(hipMemcpy(preamble0, A + opre, 4 * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(sector, A + osec, 4 * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(gain, A + ogain, 8 * n, hipMemcpyDeviceToHost));

@@ -156,7 +156,11 @@ int prach_last_timing(const prach_engine *, prach_timing *out);
  *   "lds_records"   0: clusters keep their UE records in global memory instead of LDS
  *   "fast"          0: LDS-resident clusters run on the general cluster kernel instead of prach::lcluster_kernel
  *   "batch"         0: one-workgroup-per-trial Philox launches run on the general cluster kernel instead of prach::batch_kernel
- *   "xcd_pack"      0: clusters are not launched XCD-packed;  "two_per_cu" 1: small LDS layout of the general kernel (diagnostic) */
+ *   "xcd_pack"      0: clusters are not launched XCD-packed
+ *   "batch_waves"   prach::batch_kernel's workgroup shape: 8 (512 threads, two trials per CU), 16 (1024 threads), 0 = chosen per launch
+ *   "plain_arena"   1: the device arena is one hipMalloc allocation, re-allocated when it grows (before the first call only; diagnostic)
+ *   "mem_budget_mb" arena megabytes one launch may take (default: three quarters of the device's memory): a call that needs more runs as several launches
+ *   "calendar_cap", "vmm_fail_after", "noma_ambiguity_test", "noma_host_activation"   test hooks (prach_engine.hip) */
 int prach_engine_set(prach_engine *, const char *key, int64_t value);
 
 /* Host-side pieces of the same seam (no device needed) */

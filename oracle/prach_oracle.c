@@ -64,6 +64,14 @@ typedef struct {
     uint64_t collisionCalls;
 } ctx_t;
 
+/* Optional per-subframe census for design studies (tests/test_phase_model.py, oracle/README of the gate in profiles/r04_lcluster_phases.md): how many UEs (re)draw
+ * their preamble in a subframe (Beta.c:231,256 / :398 — what would have to MIGRATE if workgroups owned preamble buckets instead of UE ranges), how many
+ * preambleCollision calls are singletons (Beta.c:334 — the callers an index-ordered grant ranking has to bring together), how many calls there are. */
+static int32_t *census_redraws, *census_singles, *census_calls;
+static int census_n, census_t;
+void oracle_set_census(int32_t *redraws, int32_t *singles, int32_t *calls, int n) { census_redraws = redraws; census_singles = singles; census_calls = calls; census_n = n; census_t = 0; }
+#define CENSUS(arr) do { if (arr && census_t < census_n) arr[census_t]++; } while (0)
+
 static int draw(ctx_t *c, ue_t *u) {
     c->rng->consumed++;
     if (c->rng->mode == ORACLE_RNG_GLIBC) return glibc_rand(&c->rng->g);
@@ -140,7 +148,9 @@ static inline int slot_align(int subTime, int accessTime) {
 static void selectPreamble(ctx_t *c, ue_t *user, int time) {
     const oracle_cfg *k = c->cfg;
     oracle_ue *u = &user->u;
+    census_t = time;
     if (u->preamble == -1) {
+        CENSUS(census_redraws);
         u->preamble = draw(c, user) % k->nPreamble;
         u->rarWindow = 0;
         u->maxRarCounter = 0;
@@ -153,6 +163,7 @@ static void selectPreamble(ctx_t *c, ue_t *user, int time) {
         if (u->rarWindow >= k->maxRarWindow) {
             if (u->maxRarCounter >= k->maxMsg2TxCount) {
                 if (k->variant == ORACLE_VARIANT_WITHNOMA_C) c->continueFaliedUEs++; /* WithNOMA:499 */
+                CENSUS(census_redraws);
                 u->preamble = draw(c, user) % k->nPreamble;
                 u->rarWindow = 0;
                 u->maxRarCounter = 0;
@@ -194,7 +205,10 @@ static void preambleCollision(ctx_t *c, int self, int time, int *grantCheck) {
     } else {
         check = c->cnt[p] + 1;
     }
+    census_t = time;
+    CENSUS(census_calls);
     if (check == 1) {
+        CENSUS(census_singles);
         c->totalPreambleTxop++;
         *grantCheck = *grantCheck + 1;
         if (*grantCheck < k->nGrantUL) {
@@ -254,6 +268,8 @@ static void requestResourceAllocation(ctx_t *c, ue_t *user, int time) {
         u->txTime = slot_align(subTime, 5); /* hard-coded accessTime = 5, Beta.c:389 */
         u->active = 1;
         u->nowBackoff = u->txTime - time;
+        census_t = time;
+        CENSUS(census_redraws);
         u->preamble = draw(c, user) % k->nPreamble;
         u->timer = 0;
         u->msg2Flag = 0;

@@ -1,18 +1,33 @@
 #!/usr/bin/env bash
-# scripts/gpu_round_checks.sh — run ON THE GPU BOX (gpurun): the GPU parity suite plus every fuzzer on the build that is in the tree
-# (general kernels in both RNG modes, the lean cluster kernel, big trials, the batch kernel in both workgroup shapes, in the reference's stream and with the
-# 128-entry-queue test build).  Every fuzzer prints "... N bad"; the lean / batch ones also how many trials left their kernel.
-set -e
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-python3 tests/tools/gpu_fuzz.py 61 400 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_lean.py 62 200 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_lean.py 65 30 big 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_big.py 63 20 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_batch.py 64 60 2>&1 | grep -v "^\[prach\]" | tail -1
-PRACH_ENG_OPTS=batch_waves=8 python3 tests/tools/gpu_fuzz_batch.py 66 40 2>&1 | grep -v "^\[prach\]" | tail -1
-PRACH_LIB=$GRAFT_REPO_ROOT/5g-nr-randomaccess_amd/libprach_hip_tinyq.so python3 tests/tools/gpu_fuzz_batch.py 67 40 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_batch.py 68 10 big 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_batch.py 70 60 small glibc 2>&1 | grep -v "^\[prach\]" | tail -1
-PRACH_LIB=$GRAFT_REPO_ROOT/5g-nr-randomaccess_amd/libprach_hip_tinyq.so python3 tests/tools/gpu_fuzz_batch.py 77 30 small glibc 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_noma.py 69 60 2>&1 | grep -v "^\[prach\]" | tail -1
-python3 tests/tools/gpu_fuzz_noma.py 78 60 glibc 2>&1 | grep -v "^\[prach\]" | tail -1
+# scripts/gpu_round_checks.sh — run ON THE GPU BOX (gpurun): the GPU parity suite plus every fuzzer on the build that is in the tree (general kernels in both
+# RNG modes, the lean cluster kernel, big trials, the batch kernel in both workgroup shapes, in the reference's stream and with the small-list test build, NOMA.c
+# in both streams).  Every step's full log goes to gpurun_out/checks/; the script exits non-zero if pytest fails or a fuzzer's last line does not say " 0 bad".
+set -uo pipefail
+OUT=gpurun_out/checks
+mkdir -p "$OUT"
+fail=0
+python -m pytest tests -m gpu -q > "$OUT/pytest.log" 2>&1 || fail=1
+tail -2 "$OUT/pytest.log"
+fz() { # name, command...
+  local name="$1"; shift
+  ( "$@" ) > "$OUT/fuzz_$name.log" 2>&1
+  local rc=$?
+  local last; last=$(grep -v "^\[prach\]" "$OUT/fuzz_$name.log" | tail -1)
+  echo "$name: $last"
+  [[ $rc -eq 0 && "$last" == *" 0 bad"* ]] || { echo "  ^ FAILED (exit $rc)"; fail=1; }
+}
+TQ=$GRAFT_REPO_ROOT/5g-nr-randomaccess_amd/libprach_hip_tinyq.so
+N=${FUZZ_SCALE:-1}
+fz general      timeout -k 10 900 python3 tests/tools/gpu_fuzz.py 61 $((400 * N))
+fz lean         timeout -k 10 900 python3 tests/tools/gpu_fuzz_lean.py 62 $((200 * N))
+fz lean_big     timeout -k 10 900 python3 tests/tools/gpu_fuzz_lean.py 65 $((30 * N)) big
+fz big          timeout -k 10 900 python3 tests/tools/gpu_fuzz_big.py 63 $((20 * N))
+fz batch        timeout -k 10 900 python3 tests/tools/gpu_fuzz_batch.py 64 $((60 * N))
+fz batch_w8     env PRACH_ENG_OPTS=batch_waves=8 timeout -k 10 900 python3 tests/tools/gpu_fuzz_batch.py 66 $((40 * N))
+fz batch_tinyq  env PRACH_LIB=$TQ timeout -k 10 900 python3 tests/tools/gpu_fuzz_batch.py 67 $((40 * N))
+fz batch_big    timeout -k 10 900 python3 tests/tools/gpu_fuzz_batch.py 68 $((10 * N)) big
+fz batch_glibc  timeout -k 10 900 python3 tests/tools/gpu_fuzz_batch.py 70 $((60 * N)) small glibc
+fz batch_glibc_tinyq env PRACH_LIB=$TQ timeout -k 10 900 python3 tests/tools/gpu_fuzz_batch.py 77 $((30 * N)) small glibc
+fz noma         timeout -k 10 900 python3 tests/tools/gpu_fuzz_noma.py 69 $((60 * N))
+fz noma_glibc   timeout -k 10 900 python3 tests/tools/gpu_fuzz_noma.py 78 $((60 * N)) glibc
+exit $fail

@@ -353,3 +353,23 @@ def test_gpu_noma_glibc_equals_oracle(pkg, ob, engine):
                 engine.set(key, 0)
             assert (res2.nSuccessUE, res2.sumTimer, res2.draws, res2.time_exit, res2.steps) == (res.nSuccessUE, res.sumTimer, res.draws, res.time_exit, res.steps)
             assert bytes(logs2) == bytes(logs)
+
+
+@pytest.mark.gpu
+def test_gpu_noma_radius_just_above_the_exclusion_zone(pkg, ob, engine, capfd):
+    """cellRadius = 35.01 is a valid configuration (NOMA.c:167-172 redraws the distance until it exceeds 35 m: ~1 750 draws per UE here): the device's redraw
+    loop gives up after 4 096 iterations and flags such a UE for the host — every tenth one, more than the kernel's list holds.  The engine then builds the
+    launch's activation table on the host (the path a NOMA_AMBIGUOUS rerun takes) instead of failing: results equal the oracle's, one line on stderr."""
+    n = 100000
+    cfg = pkg.make_cfg(n, variant=pkg.VARIANT_NOMA_C, rng_mode=pkg.RNG_PHILOX, seed=5, cellRadius=35.01, max_steps=600)
+    capfd.readouterr()
+    (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
+    err = capfd.readouterr().err
+    assert "the activation table of this launch is built on the host" in err
+    ocfg = ob.make_noma_cfg(n, cellRadius=35.01, max_steps=600)
+    ores, oues = ob.noma_run_trial(ocfg, ob.Rng(ob.RNG_PHILOX, 5), want_ues=True)
+    assert (res.status, res.nSuccessUE, res.sumTimer, res.preambleTxCount, res.failCounts, res.activeCheck, res.draws, res.time_exit) == \
+           (0, ores.nSuccessUE, ores.delay, ores.nTxP, ores.raFailedUEs, ores.activeCheck, ores.draws, ores.time_exit)
+    a = np.frombuffer(logs, dtype=np.int32).reshape(-1, 16)
+    b = np.frombuffer(oues, dtype=np.dtype([("i", np.int32, 16), ("g", np.float64)]))["i"]
+    assert (a == b).all()

@@ -46,3 +46,22 @@ def test_model_stream_offset(ob):
     r2, u2 = ob.model_run_trial(cfg, ob.RNG_GLIBC, 4, stream, off, 16)
     assert r1.nSuccessUE == r2.nSuccessUE and r1.draws == r2.draws
     assert bytes(u1) == bytes(u2)
+
+
+def test_oracle_census_counts_every_call(ob):
+    """The design-study census of the oracle (oracle/census_gate.py, profiles/r04_lcluster_phases.md): its per-subframe call counts add up to the oracle's
+    own collisionCalls, singleton calls are calls, and every UE that transmitted drew a preamble at least once."""
+    import ctypes as C
+    L = ob.lib()
+    L.oracle_set_census.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.oracle_set_census.restype = None
+    T = 10000
+    red, sing, calls = (np.zeros(T, dtype=np.int32) for _ in range(3))
+    L.oracle_set_census(red.ctypes.data, sing.ctypes.data, calls.ctypes.data, T)
+    try:
+        res, ues = ob.run_trial(ob.make_cfg(6000, variant=1), ob.Rng(ob.RNG_PHILOX, 3))
+    finally:
+        L.oracle_set_census(None, None, None, 0)
+    assert int(calls.sum()) == int(res.as_dict()["collisionCalls"]) and (sing <= calls).all() and sing.sum() > 0
+    u = np.frombuffer(ues, dtype=np.int32).reshape(-1, 16)
+    assert int(red.sum()) >= int((u[:, 7] >= 0).sum())  # (column 7: preamble; -1 = never drew one)
