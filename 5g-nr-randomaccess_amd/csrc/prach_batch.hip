@@ -166,8 +166,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     PRACH_G v4i_t *const rec32 = (PRACH_G v4i_t *)PD->rec32;     // [nUE][2] a UE's record at home: before it arrives, and once it has finished
     PRACH_G v4i_t *const chunks = (PRACH_G v4i_t *)PD->chunks;   // [nchunks][CHUNK] the pool of 2 KB chunks
     PRACH_G int *const ctab = (PRACH_G int *)PD->ctab;           // [calmask + 1][tcap] chunk table: the chunks of every future subframe's event list
-    PRACH_G int *const cpool = (PRACH_G int *)PD->cpool;         // [2][nchunks] shared pool of free chunk ids (what the wavefronts' own stacks cannot take)
-    const int nchunks = PD->nchunks, tcap = PD->tcap;
+    const int tcap = PD->tcap;                                   // (PD->cpool [2][nchunks]: the shared pool of free chunk ids, what the wavefronts' own stacks cannot take)
     PRACH_G int *const jcal = (PRACH_G int *)PD->jcal;           // [calmask + 1][calcap] join lists
     const int calcap = PD->calcap;
     const unsigned calmask = (unsigned)PD->calmask;
@@ -192,6 +191,22 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     unsigned long long base = 0; // GLIBC: rand() calls consumed so far (relative to the stream window)
 
     const int totgroups = (nUE + 63) >> 6;
+    // The event body's constants (divisor magics, the Philox key, list capacities, the pointers of the rarely taken paths) are wave-uniform: as such they would
+    // sit in scalar registers across the whole step loop, where the budget of 102 is spent twice over (159 spilled scalars: a v_readlane / v_writelane pair around
+    // every use) — and the scalar side is what bounds this kernel (profiles/r04_grid.md).  Held in vector registers (the wavefront has ~35 to spare at four
+    // wavefronts per SIMD) they cost nothing to use: a VALU operand either way.
+#define B_TO_VGPR(x) asm volatile("" : "+v"(x))
+    unsigned vseed_lo = seed_lo, vseed_hi = seed_hi;
+    int vnUE = nUE, vvariant = variant, vcalcap = calcap, vtcap = tcap;
+    B_TO_VGPR(vseed_lo); B_TO_VGPR(vseed_hi); B_TO_VGPR(vnUE); B_TO_VGPR(vvariant); B_TO_VGPR(vcalcap); B_TO_VGPR(vtcap);
+    B_TO_VGPR(K.fmP.d); B_TO_VGPR(K.fmP.M); B_TO_VGPR(K.fmB.d); B_TO_VGPR(K.fmB.M); B_TO_VGPR(K.fmA.d); B_TO_VGPR(K.fmA.M); B_TO_VGPR(K.fm5.d); B_TO_VGPR(K.fm5.M);
+    B_TO_VGPR(K.maxMsg2);
+    PRACH_G int *vjcal = jcal, *vctab = ctab;
+    B_TO_VGPR(vjcal); B_TO_VGPR(vctab);
+#undef B_TO_VGPR
+    // ... and what only the rare paths need (the shared chunk pool, the global parts of the lists, a finished UE's home) is read from the parameter block where it
+    // is used — an opaque copy of the block's address keeps the compiler from hoisting those loads back out of the step loop into scalar registers
+    auto rare = [&]() __attribute__((always_inline)) -> const TrialDev * { const TrialDev *q = PD; asm volatile("" : "+s"(q)); return q; };
     // calloc + initialUE (Beta.c:78-83)
     for (int i = tid; i < nUE; i += TB) { st_i4(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0)); st_i4(rec32 + 2 * (size_t)i + 1, make_int4(0, 0, 0, (int)PW_IDLE)); }
     for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; rg[k] = -1; }
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     int pool_parity = 0; // (this subframe's parity, for the shared pool's halves)
     auto chunk_free = [&](const int id) __attribute__((always_inline)) { // wave-uniform
         if (sp < 64) { stash = lane == sp ? id : stash; sp++; }
-        else if (lane == 0) { const int h = atomicAdd(&scal[B_POOLH + pool_parity], 1); if (h >= 0 && h < nchunks) cpool[(size_t)pool_parity * (size_t)nchunks + (size_t)h] = id; }
+        else if (lane == 0) { const int h = atomicAdd(&scal[B_POOLH + pool_parity], 1); { const TrialDev *q = rare(); if (h >= 0 && h < q->nchunks) ((PRACH_G int *)q->cpool)[(size_t)pool_parity * (size_t)q->nchunks + (size_t)h] = id; } }
     };
     auto chunk_alloc = [&]() __attribute__((always_inline)) -> int { // wave-uniform
         if (sp > 0) { sp--; return __builtin_amdgcn_readlane(stash, sp); }
@@ -229,10 +244,12 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         if (lane == 0) { // the shared pool's half that was filled in the previous subframe, then chunks never used before
             const int side = pool_parity ^ 1;
             const int h = atomicSub(&scal[B_POOLH + side], 1);
-            if (h > 0 && h <= nchunks) id = __hip_atomic_load(cpool + (size_t)side * (size_t)nchunks + (size_t)(h - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const TrialDev *q = rare();
+            const int nch_ = q->nchunks;
+            if (h > 0 && h <= nch_) id = __hip_atomic_load((PRACH_G int *)q->cpool + (size_t)side * (size_t)nch_ + (size_t)(h - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else {
                 id = atomicAdd(&scal[B_BUMP], 1);
-                if (id >= nchunks - 1) { scal[B_OVF] = 1; id = nchunks - 1; } // (the pool's last chunk takes what no longer matters: the trial leaves behind S2)
+                if (id >= nch_ - 1) { scal[B_OVF] = 1; id = nch_ - 1; } // (the pool's last chunk takes what no longer matters: the trial leaves behind S2)
             }
         }
         return __builtin_amdgcn_readfirstlane(id);
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         if (lane == 0) {
             const int sl = (int)((unsigned)te & calmask);
             const int seq = atomicAdd(&nchk[sl], 1);
-            if (seq < tcap) ctab[(size_t)sl * (size_t)tcap + (size_t)seq] = id | (count << 24);
+            if (seq < vtcap) vctab[(size_t)sl * (size_t)vtcap + (size_t)seq] = id | (count << 24);
             else scal[B_OVF] = 1;
         }
     };
@@ -297,19 +314,24 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         BSTAMP(0); // loop head
 
         // ================= joins: UEs whose contention window opens in this subframe enter the ring's subframes t .. t + dur - 1 =================
-        for (int q0 = (NWB - 1 - w) * 64; q0 < nj; q0 += NWB * 64) { // (from the last wavefront down: the first ones have the most event batches)
-            const int q = q0 + lane;
-            int je = 0;
-            if (q < nj) je = jcal[(size_t)slot * (size_t)calcap + (size_t)q];
-            const int i = je & 0xFFFFF, p = (je >> 20) & 63;
-            int dur = (int)((unsigned)je >> 26);
-            if (q >= nj || granted_at(i, p, t - 1, t - 1) >= 0) dur = 0; // (granted in the subframe it was scheduled in: out of contention, Beta.c:338-343)
-            const int dmax = wave_max(dur);
-            for (int k = 0; k < dmax; k++) {
-                if (k < dur) {
-                    const int rs = ((t + k) & (HRING - 1)) * NPB + p;
-                    atomicAdd(&hr[rs], 1);
-                    atomicMin(&mr[rs], (i << 6) | (dur - 1 - k));
+        { // (from the last wavefront down: the first ones have the most event batches; the next batch's entries are in flight while this one's atomics are issued)
+            const PRACH_G int *const jl = jcal + (size_t)slot * (size_t)calcap;
+            const int qs = (NWB - 1 - w) * 64;
+            int je_n = qs + lane < nj ? jl[qs + lane] : 0;
+            for (int q0 = qs; q0 < nj; q0 += NWB * 64) {
+                const int q = q0 + lane;
+                const int je = je_n;
+                je_n = q + NWB * 64 < nj ? jl[q + NWB * 64] : 0;
+                const int i = je & 0xFFFFF, p = (je >> 20) & 63;
+                int dur = (int)((unsigned)je >> 26);
+                if (q >= nj || granted_at(i, p, t - 1, t - 1) >= 0) dur = 0; // (granted in the subframe it was scheduled in: out of contention, Beta.c:338-343)
+                const int dmax = wave_max(dur);
+                for (int k = 0; k < dmax; k++) {
+                    if (k < dur) {
+                        const int rs = ((t + k) & (HRING - 1)) * NPB + p;
+                        atomicAdd(&hr[rs], 1);
+                        atomicMin(&mr[rs], (i << 6) | (dur - 1 - k));
+                    }
                 }
             }
         }
@@ -356,7 +378,10 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                 if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i << 6);
                 if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i << 6);
                 {
-                    const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(o.eclass);
+                    // (an early leaver matters only below its bucket's lowest caller, Beta.c:321-330: the lowest matched index only falls during the subframe, so a UE
+                    //  at or above what it is NOW — this wavefront's joins are all in, the others' nearly — can be dropped here; the rest is looked at again behind S1)
+                    const bool cand_ = o.eclass && i < (mlocx[o.oldp] >> 6);
+                    const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(cand_);
                     if (em | cm) {
                         int b_ev = 0, b_cd = 0;
                         if (lane == 0) {
@@ -368,9 +393,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                             const int es = b_ev + __popcll(em & lanemask_lt(lane));
                             ev_set(es, i, ue_event_info(o));
                         }
-                        if (o.eclass) {
+                        if (cand_) {
                             const int cs = b_cd + __popcll(cm & lanemask_lt(lane)), cv = i | (o.oldp << 20);
-                            if (cs < CCAP) candl[cs] = cv; else candg[cs - CCAP] = cv;
+                            if (cs < CCAP) candl[cs] = cv; else ((PRACH_G int *)rare()->qov)[cs - CCAP] = cv;
                         }
                     }
                 }
@@ -415,11 +440,12 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     PRACH_G v4i_t *const c = chunks + (size_t)cid * CHUNK + cpos;
                     st_i4(c, pack(u)); st_i4(c + 64, cold_pack(nd, durn, cold, i));
                     if (durn > 0u) {
-                        if (jp < calcap) jcal[(size_t)js * (size_t)calcap + (size_t)jp] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
+                        if (jp < vcalcap) vjcal[(size_t)js * (size_t)vcalcap + (size_t)jp] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
                         else scal[B_OVF] = 1;
                     }
                 } else if (v) { // home: finished for good (or never to be looked at again)
-                    st_i4(rec32 + 2 * (size_t)i, pack(u)); st_i4(rec32 + 2 * (size_t)i + 1, cold_pack(nd, 0u, cold, (int)word));
+                    PRACH_G v4i_t *const home = (PRACH_G v4i_t *)rare()->rec32 + 2 * (size_t)i;
+                    st_i4(home, pack(u)); st_i4(home + 1, cold_pack(nd, 0u, cold, (int)word));
                 }
             };
             // MODE 0: Philox, everything in one pass.  MODE 1 (GLIBC): the count pass — nothing is stored but the calling lanes.  MODE 2 (GLIBC): the full
@@ -480,8 +506,8 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                             if (pl.need > 1) d2 = stream[o_ + 1];
                         }
                     } else if (__any(pl.need > 0)) {
-                        d1 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd, (unsigned)nUE, (unsigned)variant);
-                        if (__any(pl.need > 1)) d2 = philox_draw31(seed_lo, seed_hi, (unsigned)i, nd + 1u, (unsigned)nUE, (unsigned)variant);
+                        d1 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd, (unsigned)vnUE, (unsigned)vvariant);
+                        if (__any(pl.need > 1)) d2 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd + 1u, (unsigned)vnUE, (unsigned)vvariant);
                         nd += (unsigned)pl.need;
                     }
                     const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
@@ -848,6 +874,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     // the event body would have (pw_catch_up).  Then end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of every UE from its home record.
     const int tend = tlast + 1;
     if (status == PRACH_OK && tlast >= 0) {
+#pragma nounroll
         for (int k = 0; k < 64; k++) { // every open chunk of this wavefront joins its subframe's list
             const int id = __builtin_amdgcn_readlane(o_id, k), meta = __builtin_amdgcn_readlane(o_meta, k);
             if (id >= 0) chunk_close(id, meta & 0xFFFF, meta >> 16);
