@@ -229,8 +229,18 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
 #endif
     // ---- this wavefront's chunk bookkeeping, in three vector registers (lane = table position) and one scalar ----
-    int o_id = -1;   // lane k: the chunk this wavefront is filling for the subframe te with (te & 63) == k; -1: none
-    int o_meta = 0;  // lane k: te (16 bits) | records in it << 16
+    // table position k = te & 127 (a UE is scheduled at most ~110 subframes ahead with the fuzzers' largest backoff: no two live subframes share a position; if
+    // two ever do, the older chunk goes to its list as it is): positions [0, 64) in o_id / o_meta, [64, 128) in o_id1 / o_meta1
+    int o_id = -1, o_id1 = -1;   // lane: the chunk this wavefront is filling for the subframe te; -1: none
+    int o_meta = 0, o_meta1 = 0; // lane: te (16 bits) | records in it << 16
+    auto open_get = [&](const int k, int &id, int &meta) __attribute__((always_inline)) { // k wave-uniform
+        if (k < 64) { id = __builtin_amdgcn_readlane(o_id, k); meta = __builtin_amdgcn_readlane(o_meta, k); }
+        else { id = __builtin_amdgcn_readlane(o_id1, k - 64); meta = __builtin_amdgcn_readlane(o_meta1, k - 64); }
+    };
+    auto open_set = [&](const int k, const int id, const int meta) __attribute__((always_inline)) {
+        if (k < 64) { o_id = lane == k ? id : o_id; o_meta = lane == k ? meta : o_meta; }
+        else { o_id1 = lane == k - 64 ? id : o_id1; o_meta1 = lane == k - 64 ? meta : o_meta1; }
+    };
     int stash = 0;   // lanes [0, sp): free chunk ids (a chunk is free as soon as its records are in registers; the wavefront that read it fills it again)
     int sp = 0;
     int pool_parity = 0; // (this subframe's parity, for the shared pool's halves)
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             if (h > 0 && h <= nch_) id = __hip_atomic_load((PRACH_G int *)q->cpool + (size_t)side * (size_t)nch_ + (size_t)(h - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else {
                 id = atomicAdd(&scal[B_BUMP], 1);
-                if (id >= nch_ - 1) { scal[B_OVF] = 1; id = nch_ - 1; } // (the pool's last chunk takes what no longer matters: the trial leaves behind S2)
+                if (id >= nch_ - 1) { scal[B_OVF] = 5; id = nch_ - 1; } // (the pool's last chunk takes what no longer matters: the trial leaves behind S2)
             }
         }
         return __builtin_amdgcn_readfirstlane(id);
@@ -259,16 +269,17 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             const int sl = (int)((unsigned)te & calmask);
             const int seq = atomicAdd(&nchk[sl], 1);
             if (seq < vtcap) vctab[(size_t)sl * (size_t)vtcap + (size_t)seq] = id | (count << 24);
-            else scal[B_OVF] = 1;
+            else scal[B_OVF] = 4;
         }
     };
     // this wavefront's open chunk of subframe te, if it has one, joins that subframe's list (behind S1 of te - 1: nothing is appended to it any more)
     auto chunk_flush = [&](const int te) __attribute__((always_inline)) {
-        const int k = te & 63;
-        const int id = __builtin_amdgcn_readlane(o_id, k), meta = __builtin_amdgcn_readlane(o_meta, k);
+        const int k = te & 127;
+        int id, meta;
+        open_get(k, id, meta);
         if (id >= 0 && (meta & 0xFFFF) == (te & 0xFFFF)) {
             chunk_close(id, te, meta >> 16);
-            o_id = lane == k ? -1 : o_id;
+            open_set(k, -1, 0);
         }
     };
     // was UE i (bucket p) given an UL grant in one of the subframes [s0, s1] (s1 - s0 < 16, s1 at most 15 subframes old)?  The subframe, or -1.
@@ -415,9 +426,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     while (todo) {
                         const int te0 = __builtin_amdgcn_readlane(te, __ffsll((long long)todo) - 1);
                         const unsigned long long mm = __ballot(sched_ && te == te0);
-                        const int c = __popcll(mm), k = te0 & 63;
-                        int id = __builtin_amdgcn_readlane(o_id, k);
-                        const int meta = __builtin_amdgcn_readlane(o_meta, k);
+                        const int c = __popcll(mm), k = te0 & 127;
+                        int id, meta;
+                        open_get(k, id, meta);
                         int fill = meta >> 16;
                         if (id >= 0 && (meta & 0xFFFF) != (te0 & 0xFFFF)) { chunk_close(id, meta & 0xFFFF, fill); id = -1; } // (another subframe sits at this table position: it goes to its list as it is)
                         if (id < 0) { id = chunk_alloc(); fill = 0; }
@@ -430,8 +441,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                         }
                         if (c >= room) { chunk_close(id, te0, 64); id = id2; fill = c - room; } // (id2 = -1, fill = 0 when it is exactly full)
                         else fill += c;
-                        o_id = lane == k ? id : o_id;
-                        o_meta = lane == k ? ((te0 & 0xFFFF) | (fill << 16)) : o_meta;
+                        open_set(k, id, (te0 & 0xFFFF) | (fill << 16));
                         todo &= ~mm;
                     }
                 }
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         BSTAMP(5); // leaver filter
         __syncthreads(); // S2
         BSTAMP(6);
-        if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = scal[B_OVF] == 1 ? 5 : 6; time_exit = t; break; } // the chunk pool, a chunk table or a join list was full
+        if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = 4 + scal[B_OVF]; time_exit = t; break; } // 5 a join list, 6 the grant notes, 8 a chunk table, 9 the chunk pool: full
         const int N = scal[B_NEV + parity];
         if (tid < NPB) { histx[tid] = 0; mlocx[tid] = INT_MAX; } // (this ring row is the subframe t + HRING from here on: joined at t + 2 at the earliest)
         const int nsucc_tot = scal[B_NSUCC];
@@ -867,7 +877,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         if (nsucc_tot == nUE) { time_exit = t; break; } // Beta.c:180
     }
     __syncthreads();
-    if (status == PRACH_OK && scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = scal[B_OVF] == 1 ? 5 : 6; time_exit = tlast; } // (raised by the last subframe's grants)
+    if (status == PRACH_OK && scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = 4 + scal[B_OVF]; time_exit = tlast; } // (raised by the last subframe's grants)
 
     // ---- the state after the last subframe.  Records still on their way (in some later subframe's list, or in a wavefront's open chunk) go home first: the
     // deferred outcome of the last subframe (or the grant noted for them) and the subframes they were matched in since they were scheduled are applied, as
@@ -875,8 +885,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     const int tend = tlast + 1;
     if (status == PRACH_OK && tlast >= 0) {
 #pragma nounroll
-        for (int k = 0; k < 64; k++) { // every open chunk of this wavefront joins its subframe's list
-            const int id = __builtin_amdgcn_readlane(o_id, k), meta = __builtin_amdgcn_readlane(o_meta, k);
+        for (int k = 0; k < 128; k++) { // every open chunk of this wavefront joins its subframe's list
+            int id, meta;
+            open_get(k, id, meta);
             if (id >= 0) chunk_close(id, meta & 0xFFFF, meta >> 16);
         }
         __syncthreads();
@@ -947,7 +958,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         o->ptcSum = scal[B_PTC]; o->fcSum = scal[B_FC];
         o->nSuccess = scal[B_NSUCC]; o->finalSuccess = scal[B_NSUCC]; o->continueFailed = scal[B_CONTF];
         o->status = status;
-        o->hard_error = why; // (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 the chunk pool / a chunk table / a join list, 6 the grant notes: reported by the engine)
+        o->hard_error = why; // (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 a join list, 6 the grant notes, 8 a chunk table, 9 the chunk pool: reported by the engine)
         o->time_exit = time_exit;
         o->collisionPreambles = scal[B_COLL]; o->totalPreambleTxop = scal[B_TXOP];
         o->activeCheck = activeCheck;

@@ -154,16 +154,16 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
         T.calcap = T.calslots = T.npool = T.tcap = 0;
         if (batch) { // prach_batch.hip: 32-byte event records, the two calendars, the global parts of the candidate and event lists
             // The records of the UEs under way travel in 2 KB chunks of 64: every UE has one record, so ceil(nUE / 64) full chunks, plus the open chunks of the
-            // wavefronts (at most 64 each), plus what sits in their stacks of free ids (64 each), plus slack: twice the full chunks + 2 112.  A join list holds
+            // wavefronts (at most 128 each), plus what sits in their stacks of free ids (64 each), plus slack: twice the full chunks + 3 136.  A join list holds
             // the UEs whose window opens in ONE subframe: txTime is aligned to the access slots (Beta.c:268-277), so an overloaded trial (more UEs than its UL
             // grants can serve: every UE cycles through backoff and window about every 17 subframes) puts ~0.3 nUE into one list, another trial far less.
             // A trial that exhausts either leaves with PRACH_ERR_INTERNAL and is rerun with a doubled pool and lists of nUE entries (run_trials_impl).
             T.calslots = batch_calendar_slots(c.backoff, c.accessTime, c.maxRarWindow);
             const double steps_ = (double)((c.max_steps > 0 && c.max_steps < prach_max_time(&c)) ? c.max_steps : prach_max_time(&c));
             const bool overloaded = (double)c.nUE > (double)std::max(0, c.nGrantUL - 1) * steps_ / 5.0;
-            T.calcap = (int)std::min(n, std::max<size_t>(4096, overloaded ? n * 2 / 5 : n / 8)) + 64;
+            T.calcap = (int)(n <= 16384 ? n : std::max<size_t>(16384, overloaded ? n * 2 / 5 : n / 8)) + 64; // (a small trial gets lists that cannot fill)
             if (calendar_cap > 0) T.calcap = (int)calendar_cap;
-            T.npool = 2 * (int)((n + 63) / 64) + 2 * 16 * 64 + 64;
+            T.npool = 2 * (int)((n + 63) / 64) + 16 * (128 + 64) + 64;
             if (full_calendars) { T.calcap = (int)n + 64; T.npool *= 2; }
             T.tcap = (int)((n + 63) / 64) + 256;
             T.rec32 = take(32 * n); T.chunks = take((size_t)batch_chunk_bytes() * (size_t)T.npool); T.ctab = take(4 * (size_t)T.calslots * (size_t)T.tcap);
@@ -698,9 +698,9 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         }
         if (dr.status != PRACH_OK && e->last.rec_mode == CLUSTER_REC_LFAST && std::getenv("PRACH_VERBOSE"))
             std::fprintf(stderr, "[prach] lcluster_kernel: trial nUE=%d left at subframe %d with status %d, capacity code %d\n", c.nUE, dr.time_exit, dr.status, dr.hard_error);
-        if (batch && dr.status == PRACH_ERR_INTERNAL && dr.hard_error == 5 && !e->full_calendars) e->cal_overflow.push_back(idx[k]);
+        if (batch && dr.status == PRACH_ERR_INTERNAL && (dr.hard_error == 5 || dr.hard_error == 8 || dr.hard_error == 9) && !e->full_calendars) e->cal_overflow.push_back(idx[k]);
         if (dr.status == PRACH_ERR_INTERNAL && e->last.rec_mode == CLUSTER_REC_BATCH && std::getenv("PRACH_VERBOSE"))
-            std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d left at subframe %d: capacity %d (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 the chunk pool / a chunk table / a join list, 6 the grant notes)\n", c.nUE, dr.time_exit, dr.hard_error);
+            std::fprintf(stderr, "[prach] batch_kernel: trial nUE=%d (P %d B %d G %d R %d M %d A %d u %d) left at subframe %d: capacity %d (2 reset-cycle candidates, 3 singleton callers, 4 crossing bin, 5 a join list, 6 the grant notes, 8 a chunk table, 9 the chunk pool)\n", c.nUE, c.nPreamble, c.backoff, c.nGrantUL, c.maxRarWindow, c.maxMsg2TxCount, c.accessTime, c.uniform, dr.time_exit, dr.hard_error);
         if (dr.status != PRACH_OK) continue;
         // totalDelay is a FLOAT running sum in index order (Beta.c:186,193): exact in integer
         // arithmetic while it stays below 2^24, otherwise replay the float additions on the host.
