@@ -213,6 +213,24 @@ def checked_traffic(prof, rec_mode: int, k_ms: float):
                                                   f"{prof_ms:.2f} ms under the profiler vs {k_ms:.2f} ms here")
 
 
+def batch_traffic(workload: str, rec_mode: int, updates: float, kernel_ms: float):
+    """Counter-measured HBM bytes of a batch_kernel launch, scaled from the profiled launch of the same regime (profiles/traffic_batch.json: bytes per UE-subframe
+    update of the 1000-trial grid / of config 3) to this launch's updates — carried only while the kernel is prach::batch_kernel and its update rate is within
+    15 % of the profiled launch's (a launch of another size has another tail, hence the wider band than for the single-trial line); else null and the reason."""
+    tf = os.path.join(ROOT, "profiles", "traffic_batch.json")
+    if not os.path.exists(tf):
+        return None, "no profiles/traffic_batch.json"
+    prof = json.load(open(tf))
+    w = prof.get("workloads", {}).get(workload)
+    if rec_mode != 4 or w is None or "batch_kernel" not in prof.get("kernel", ""):
+        return None, f"profiles/traffic_batch.json holds prach::batch_kernel's {list(prof.get('workloads', {}))}: not this launch"
+    rate = updates / (kernel_ms * 1e-3)
+    if abs(rate / w["kernel_updates_per_s"] - 1.0) > 0.15:
+        return None, f"profiles/traffic_batch.json: {w['kernel_updates_per_s']:.3e} updates/s under the profiler vs {rate:.3e} here (> 15 %): stale, not carried"
+    return w["hbm_bytes_per_update"] * updates, (f"profiles/traffic_batch.json ({prof.get('tag', '?')}, {workload}): {w['hbm_bytes_per_update']:.3f} counter bytes per update "
+                                                  f"x this launch's updates; {prof.get('method', '')}")
+
+
 def relaunch_under_torchrun(args) -> int:
     """`python bench.py --gpus N` (N > 1) without a torch.distributed rendezvous in the environment: run the same command line as
     N ranks in a child process.  Returns the child's exit code; a node with fewer than N GPUs is an error, not a smaller run."""
@@ -364,6 +382,8 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
     csv_bytes = pkg.results_csv(per_point)
     value = updates_per_step * args.steps / max_dt
     mean_rank = sum(per_rank) / len(per_rank)
+    tmr = eng.timing()
+    g_traffic, g_note = batch_traffic("grid", tmr.rec_mode, updates_per_step / world, sum(kmss) / args.steps)
     return {
         "metric": "UE-subframe updates/sec at nUE=100k Beta; bit-exact success-ratio vs ref",
         "value": value, "unit": "UE-subframe updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -382,12 +402,14 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
         # own_bytes()) and the dense-formulation rate is carried beside it, labelled.
         "roofline": {"bound": "hbm", "achieved": sum(owns) / (sum(kmss) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": sum(owns) / (sum(kmss) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "prach::batch_kernel (event lists of 32-byte records in 2 KB chunks, one workgroup per trial)", "kernel_ms_rank0": sum(kmss) / args.steps,
+                     "traffic": g_traffic, "traffic_unit": "HBM bytes per step on rank 0 (FETCH_SIZE x 2.000 + WRITE_SIZE)", "traffic_provenance": g_note,
+                     "kernel": "prach::batch_kernel (event lists of 32-byte records in 2 KB chunks, one workgroup per trial)", "kernel_ms_rank0": sum(kmss) / args.steps,
                      "bytes": "the kernel's own bytes: 64 B per event UE (its 32-byte record streamed in and out, whole 64-record chunks) + 8 B per contention window (join-list entry), rank 0",
                      "own_bytes_per_update": sum(owns) / max(1, updates_per_step * args.steps / world),
                      "dense_formulation_GBps_32B_per_update": ALGO_BYTES_PER_UPDATE * updates_per_step / world / (sum(kmss) / args.steps * 1e-3) / 1e9,
-                     "note": "counter-measured HBM traffic of this regime (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes): profiles/r03_config3.md "
-                             "(config 3: 6.3 B per update counted against 4.3 own: an event fetches a whole 128-byte line for its 32-byte record)"},
+                     "note": "the launch is bound by instruction issue on the scalar side of the event body, not by HBM (profiles/r04_grid.md: counter traffic 0.77 B per "
+                             "update = 0.95 x the kernel's own bytes, 1.6 TB/s); the 32 B per update of the reference's dense formulation is not a lower bound for a "
+                             "kernel that only touches a UE at its events (dense_formulation_GBps is carried for the record: several times the chip's peak)"},
         # The N = 1 line of the driver's scaling run is the single-trial workload (configs[1]), a DIFFERENT workload: the one-GPU figure of this
         # grid regime travels in that same N = 1 line as extras.grid_one_gpu (measured in that run, --times 100), and every N > 1 line carries
         # value_per_gpu, so that a scaling efficiency can be formed from measured records only (no constant is pasted in here).
@@ -510,16 +532,16 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
         tm3 = eng.timing()
         kms = tm3.kernel_ms
         own = own_bytes(tm3)  # the kernel's OWN bytes
+        c3_traffic, c3_note = batch_traffic("config3", tm3.rec_mode, upd, kms)
         extras["config3_sweep_x100_1000_trials"] = {
             "kernel_updates_per_s": upd / (kms * 1e-3), "kernel_ms": kms, "updates": upd,
             "algorithmic_GBps_32B_per_update": 32.0 * upd / (kms * 1e-3) / 1e9,
             "own_traffic": {"group_visits": tm3.group_visits, "event_ues": tm3.event_ues, "own_bytes": own, "own_bytes_per_update": own / upd,
                             "own_GBps": own / (kms * 1e-3) / 1e9, "frac_of_hbm_peak": own / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "counter_traffic": "profiles/: FETCH_SIZE x2 + WRITE_SIZE of the same launch (compare: bytes beyond own_bytes are waste)"},
+                            "counter_traffic_bytes": c3_traffic, "counter_traffic_provenance": c3_note},
             "kernel": KERNEL_NAMES.get(tm3.rec_mode, "?"),
-            "note": "32 B per update are the algorithmic bytes of the reference's dense formulation; the kernel skips finished / not yet arrived groups, "
-                    "reads 4 B per visited UE and touches a UE's 32-byte record only on its events, so this is NOT an HBM fraction: the counter traffic of "
-                    "this launch (FETCH_SIZE / WRITE_SIZE, separate passes) is in profiles/r03_config3.md",
+            "note": "32 B per update are the algorithmic bytes of the reference's dense formulation; the kernel touches a UE only at its events (its 32-byte record "
+                    "streamed in and out of the event lists), so this is NOT an HBM fraction: profiles/r04_grid.md",
             "mean_success_ratio_100k": sum(r_.nSuccessUE for c, r_ in zip(cfgs, rs) if c.nUE == 100000) / 100 / 1e5}
         # (3b) the sharded grid's regime on ONE GPU (the denominator of the N > 1 lines' scaling): the Beta.c program's sweep x --times 100,
         #      1000 trials in one call
@@ -529,7 +551,9 @@ def run_single(args, pkg, eng, torch, dist, rank, world, cdev, barrier):
         wall = time.perf_counter() - t1
         upd = sum(c.nUE * r_.steps for c, r_ in zip(cfgs, rs))
         tmg = eng.timing()
+        gg_traffic, gg_note = batch_traffic("grid", tmg.rec_mode, upd, tmg.kernel_ms)
         extras["grid_one_gpu"] = {"workload": "configs[4]'s grid with --times 100: 1000 Beta.c trials (nUE 10k..100k), one call, one launch", "kernel": KERNEL_NAMES.get(tmg.rec_mode, "?"),
+                                  "own_bytes": own_bytes(tmg), "counter_traffic_bytes": gg_traffic, "counter_traffic_provenance": gg_note,
                                   "kernel_updates_per_s": upd / (tmg.kernel_ms * 1e-3), "wall_updates_per_s": upd / wall, "kernel_ms": tmg.kernel_ms,
                                   "updates": upd, "trials": len(cfgs), "bad": sum(r_.status != 0 for r_ in rs), "fallback_trials": tmg.fallback_trials}
         # (4) BASELINE config 4: NOMA.c power-level grouping, nUE=100 000, one trial.  kernel_ms covers noma_activation_kernel (activeUE, NOMA.c:131-192, on the
