@@ -57,6 +57,12 @@ namespace {
 #ifndef PRACH_B_XVALU
 #define PRACH_B_XVALU 0 // (sensitivity experiment) extra Philox draws per event batch, results unused
 #endif
+#ifndef PRACH_B_XSALU
+#define PRACH_B_XSALU 0 // (sensitivity experiment) extra dependent scalar instructions per event batch
+#endif
+#ifndef PRACH_B_XBR
+#define PRACH_B_XBR 0   // (sensitivity experiment) extra exec-masked short blocks (s_and_saveexec / s_cbranch_execz / s_or) per event batch
+#endif
 #ifndef PRACH_B_XLDS
 #define PRACH_B_XLDS 0  // (sensitivity experiment) extra returning LDS atomics per event batch (on dummy words)
 #endif
@@ -110,7 +116,8 @@ template <int NWB> struct BL {
     static constexpr int NCHK = ROV + 4 * HRING * ROVCAP;  // int [CR] chunks entered into the event list of the subframes t .. (slot = subframe & calmask)
     static constexpr int JCNT = NCHK + 4 * CR;             // int [CR] entries in the join list of ...
     static constexpr int CANDL = JCNT + 4 * CR;            // int [CAND] early-leaver candidates: index | old bucket << 20
-    static constexpr int END = CANDL + 4 * C::CAND;
+    static constexpr int DUMMY = CANDL + 4 * C::CAND;      // int [64] per-lane dummy words: what a lane adds to / takes the minimum of when it has nothing to contribute
+    static constexpr int END = DUMMY + 4 * 64;
     static_assert(SIDX % 16 == 0 && HR % 16 == 0, "alignment");
 };
 static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     int *const hr = BI(bl::HR), *const mr = BI(bl::MR), *const rg = BI(bl::RG), *const rov = BI(bl::ROV);
     unsigned *const bmk = BU(bl::BM);
     int *const candl = BI(bl::CANDL);
+    int *const dummy = BI(bl::DUMMY);
     unsigned *const gm = BU(BLG::GM);  // (GLIBC only) [BGG][4]: lanes with >= 1 call (two words), lanes with 2 calls (two words)
     int *const gpre = BI(BLG::GPRE);   // (GLIBC only) [BGG]
     const PRACH_G int *const stream = (const PRACH_G int *)PD->stream;
@@ -284,18 +292,20 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     };
     // was UE i (bucket p) given an UL grant in one of the subframes [s0, s1] (s1 - s0 < 16, s1 at most 15 subframes old)?  The subframe, or -1.
     auto granted_at = [&](const int i, const int p, const int s0, const int s1) -> int {
-        const unsigned m = bmk[p];
+        // the ring's bits that stand for the subframes [max(s0, 0), s1] — n of them, from bit (lo & 15) on, wrapping — in one expression: the scalar side pays for
+        // every loop iteration and every exec-masked block of this kernel (profiles/r04_grid.md), and a grant inside a UE's own window is the rare case
+        const int lo = max(s0, 0), n = s1 - lo + 1;
+        const unsigned ones = n > 0 ? (n >= 16 ? 0xFFFFu : (1u << n) - 1u) : 0u, sh = (unsigned)lo & 15u;
+        unsigned cand = bmk[p] & (((ones << sh) | ((ones << sh) >> 16)) & 0xFFFFu);
         int found = -1;
-        if (m) {
-            for (int s = s1; s >= s0 && s >= 0; s--) {
-                if ((m >> (s & 15)) & 1u) {
-                    if (rg[(s & 15) * NPB + p] == i) found = s;
-                    else {
-                        const int n = min(scal[B_NROV + (s & 15)], ROVCAP);
-                        for (int k = 0; k < n; k++) if (rov[(s & 15) * ROVCAP + k] == (i | (p << 20))) found = s;
-                    }
-                }
+        while (cand) {
+            const int b_ = 31 - __clz((int)cand), s = lo + ((b_ - lo) & 15);
+            if (rg[b_ * NPB + p] == i) found = s;
+            else {
+                const int nr = min(scal[B_NROV + b_], ROVCAP);
+                for (int k = 0; k < nr; k++) if (rov[b_ * ROVCAP + k] == (i | (p << 20))) found = s;
             }
+            cand &= ~(1u << b_);
         }
         return found;
     };
@@ -337,12 +347,12 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                 int dur = (int)((unsigned)je >> 26);
                 if (q >= nj || granted_at(i, p, t - 1, t - 1) >= 0) dur = 0; // (granted in the subframe it was scheduled in: out of contention, Beta.c:338-343)
                 const int dmax = wave_max(dur);
+                // (lanes whose window is shorter — or that take no part — add 0 to / take the minimum of a per-lane dummy word: one exec-masked block less per round)
                 for (int k = 0; k < dmax; k++) {
-                    if (k < dur) {
-                        const int rs = ((t + k) & (HRING - 1)) * NPB + p;
-                        atomicAdd(&hr[rs], 1);
-                        atomicMin(&mr[rs], (i << 6) | (dur - 1 - k));
-                    }
+                    const bool in = k < dur;
+                    const int rs = ((t + k) & (HRING - 1)) * NPB + p;
+                    atomicAdd(in ? &hr[rs] : &dummy[lane], 1);
+                    atomicMin(in ? &mr[rs] : &dummy[lane], (i << 6) | (dur - 1 - k));
                 }
             }
         }
@@ -378,6 +388,18 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     for (int k_ = 0; k_ < PRACH_B_XVALU; k_++) x_ ^= philox_draw31(seed_lo, seed_hi, (unsigned)i, nd + 77u + (unsigned)k_, (unsigned)nUE, (unsigned)variant);
                     if (x_ == 0x7fffffff && nd == 0xfffffffu) scal[B_OVF] = 3;
                 }
+                if (PRACH_B_XSALU) {
+                    int z_ = t;
+#pragma unroll
+                    for (int k_ = 0; k_ < PRACH_B_XSALU; k_++) { asm volatile("s_mul_i32 %0, %0, 3\n\ts_add_i32 %0, %0, 1" : "+s"(z_)); }
+                    if (z_ == 0x7fffffff) scal[B_OVF] = 3;
+                }
+                if (PRACH_B_XBR) {
+                    int q_ = i;
+#pragma unroll
+                    for (int k_ = 0; k_ < PRACH_B_XBR; k_++) { if ((q_ >> (k_ & 15)) & 1) { asm volatile("v_add_u32 %0, %0, 7\n\tv_xor_b32 %0, %0, 5\n\tv_add_u32 %0, %0, 7\n\tv_xor_b32 %0, %0, 5\n\tv_add_u32 %0, %0, 7\n\tv_xor_b32 %0, %0, 5\n\tv_add_u32 %0, %0, 7\n\tv_xor_b32 %0, %0, 5\n\tv_add_u32 %0, %0, 7\n\tv_xor_b32 %0, %0, 5\n\tv_add_u32 %0, %0, 7\n\tv_xor_b32 %0, %0, 5\n\tv_add_u32 %0, %0, 7\n\tv_xor_b32 %0, %0, 5" : "+v"(q_)); } }
+                    if (q_ == 0x7ffffff1) scal[B_OVF] = 3;
+                }
                 if (PRACH_B_XLDS) {
                     int y_ = 0;
 #pragma unroll
@@ -385,9 +407,10 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     if (y_ == 0x7fffffff) scal[B_OVF] = 3;
                 }
                 // ---- bucket bookkeeping (this subframe's ring row; an event UE has nothing in the later ones: window left = 0) ----
-                if (o.member_pre) atomicAdd(&histx[o.oldp], 1);
-                if (u.pend == PEND_STAY) atomicMin(&mlocx[o.oldp], i << 6);
-                if (o.evtype == UEV_CALLER) atomicMin(&mlocx[o.evp], i << 6);
+                // (unconditional: a lane that has nothing to add hits its own dummy word — no exec-masked blocks)
+                atomicAdd(o.member_pre ? &histx[o.oldp] : &dummy[lane], 1);
+                atomicMin(u.pend == PEND_STAY ? &mlocx[o.oldp] : &dummy[lane], i << 6);
+                atomicMin(o.evtype == UEV_CALLER ? &mlocx[o.evp] : &dummy[lane], i << 6);
                 {
                     // (an early leaver matters only below its bucket's lowest caller, Beta.c:321-330: the lowest matched index only falls during the subframe, so a UE
                     //  at or above what it is NOW — this wavefront's joins are all in, the others' nearly — can be dropped here; the rest is looked at again behind S1)
@@ -435,9 +458,11 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                         const int room = 64 - fill;
                         int id2 = -1;
                         if (c > room) id2 = chunk_alloc();
-                        if ((mm >> lane) & 1ull) {
+                        {
+                            const bool mine = (mm >> lane) & 1ull;
                             const int rank = __popcll(mm & lanemask_lt(lane));
-                            if (rank < room) { cid = id; cpos = fill + rank; } else { cid = id2; cpos = rank - room; }
+                            cid = mine ? (rank < room ? id : id2) : cid;
+                            cpos = mine ? (rank < room ? fill + rank : rank - room) : cpos;
                         }
                         if (c >= room) { chunk_close(id, te0, 64); id = id2; fill = c - room; } // (id2 = -1, fill = 0 when it is exactly full)
                         else fill += c;
