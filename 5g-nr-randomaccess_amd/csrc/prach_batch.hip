@@ -117,7 +117,9 @@ template <int NWB> struct BL {
     static constexpr int JCNT = NCHK + 4 * CR;             // int [CR] entries in the join list of ...
     static constexpr int CANDL = JCNT + 4 * CR;            // int [CAND] early-leaver candidates: index | old bucket << 20
     static constexpr int DUMMY = CANDL + 4 * C::CAND;      // int [64] per-lane dummy words: what a lane adds to / takes the minimum of when it has nothing to contribute
-    static constexpr int END = DUMMY + 4 * 64;
+    static constexpr int DUMMY2 = DUMMY + 4 * 64;          // int2 [64] the same for 8-byte entries
+    static constexpr int OPENT = DUMMY2 + 8 * 64;          // int [NWB][256] per wavefront: the open chunk of every subframe ahead, (id + 1) << 8 | records in it
+    static constexpr int END = OPENT + 4 * 256 * NWB;
     static_assert(SIDX % 16 == 0 && HR % 16 == 0, "alignment");
 };
 static_assert(BL<8>::END <= 80 * 1024, "two 512-thread workgroups per CU");
@@ -211,6 +213,8 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     B_TO_VGPR(K.maxMsg2);
     PRACH_G int *vjcal = jcal, *vctab = ctab;
     B_TO_VGPR(vjcal); B_TO_VGPR(vctab);
+    int vtrash = (PD->nchunks - 1) * CHUNK, vjtrash = ((int)calmask + 1) * calcap; // where lanes with nothing to store aim: the pool's last chunk (never handed out), 64 words behind the join lists
+    B_TO_VGPR(vtrash); B_TO_VGPR(vjtrash);
 #undef B_TO_VGPR
     // ... and what only the rare paths need (the shared chunk pool, the global parts of the lists, a finished UE's home) is read from the parameter block where it
     // is used — an opaque copy of the block's address keeps the compiler from hoisting those loads back out of the step loop into scalar registers
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     for (int i = tid; i < nUE; i += TB) { st_i4(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0)); st_i4(rec32 + 2 * (size_t)i + 1, make_int4(0, 0, 0, (int)PW_IDLE)); }
     for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; rg[k] = -1; }
     for (int k = tid; k < CR; k += TB) { nchk[k] = 0; jcnt[k] = 0; }
+    for (int k = tid; k < 256 * NWB; k += TB) BI(bl::OPENT)[k] = 0;
     if (tid < NPB) {
         BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; BI(bl::FMINP)[tid] = INT_MAX; bmk[tid] = 0u;
         BI(bl::FCALL)[tid] = INT_MAX; BI(bl::FCALL)[NPB + tid] = INT_MAX; BI(bl::LCALL)[tid] = -1; BI(bl::LCALL)[NPB + tid] = -1;
@@ -236,19 +241,11 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
 #ifdef PRACH_STAMPS
     unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
 #endif
-    // ---- this wavefront's chunk bookkeeping, in three vector registers (lane = table position) and one scalar ----
-    // table position k = te & 127 (a UE is scheduled at most ~110 subframes ahead with the fuzzers' largest backoff: no two live subframes share a position; if
-    // two ever do, the older chunk goes to its list as it is): positions [0, 64) in o_id / o_meta, [64, 128) in o_id1 / o_meta1
-    int o_id = -1, o_id1 = -1;   // lane: the chunk this wavefront is filling for the subframe te; -1: none
-    int o_meta = 0, o_meta1 = 0; // lane: te (16 bits) | records in it << 16
-    auto open_get = [&](const int k, int &id, int &meta) __attribute__((always_inline)) { // k wave-uniform
-        if (k < 64) { id = __builtin_amdgcn_readlane(o_id, k); meta = __builtin_amdgcn_readlane(o_meta, k); }
-        else { id = __builtin_amdgcn_readlane(o_id1, k - 64); meta = __builtin_amdgcn_readlane(o_meta1, k - 64); }
-    };
-    auto open_set = [&](const int k, const int id, const int meta) __attribute__((always_inline)) {
-        if (k < 64) { o_id = lane == k ? id : o_id; o_meta = lane == k ? meta : o_meta; }
-        else { o_id1 = lane == k - 64 ? id : o_id1; o_meta1 = lane == k - 64 ? meta : o_meta1; }
-    };
+    // ---- this wavefront's chunk bookkeeping ----
+    // otab[te & 255] = (chunk id + 1) << 8 | records in it: the chunk this wavefront is filling for the subframe te, 0: none.  A UE is scheduled less than calmask + 1
+    // <= 256 subframes ahead and the position of subframe t + 1 is emptied in subframe t (chunk_flush): no two live subframes share a position.  A lane takes its
+    // place in the chunk with ONE atomic add on the word (finish()); only a chunk that is opened or filled up takes wave-uniform work.
+    int *const otab = BI(bl::OPENT) + w * 256;
     int stash = 0;   // lanes [0, sp): free chunk ids (a chunk is free as soon as its records are in registers; the wavefront that read it fills it again)
     int sp = 0;
     int pool_parity = 0; // (this subframe's parity, for the shared pool's halves)
@@ -272,31 +269,33 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         }
         return __builtin_amdgcn_readfirstlane(id);
     };
-    auto chunk_close = [&](const int id, const int te, const int count) __attribute__((always_inline)) { // wave-uniform: the chunk joins subframe te's event list
-        if (lane == 0) {
-            const int sl = (int)((unsigned)te & calmask);
-            const int seq = atomicAdd(&nchk[sl], 1);
-            if (seq < vtcap) vctab[(size_t)sl * (size_t)vtcap + (size_t)seq] = id | (count << 24);
-            else scal[B_OVF] = 4;
-        }
+    // the chunk joins subframe te's event list (called by the lanes that have one to enter: lane 0 for the wavefront's, every lane its own in the epilogue)
+    auto chunk_enter = [&](const int id, const int te, const int count) __attribute__((always_inline)) {
+        const int sl = (int)((unsigned)te & calmask);
+        const int seq = atomicAdd(&nchk[sl], 1);
+        if (seq < vtcap) vctab[(size_t)sl * (size_t)vtcap + (size_t)seq] = id | (count << 24);
+        else scal[B_OVF] = 4;
     };
+    auto chunk_close = [&](const int id, const int te, const int count) __attribute__((always_inline)) { if (lane == 0) chunk_enter(id, te, count); }; // wave-uniform
     // this wavefront's open chunk of subframe te, if it has one, joins that subframe's list (behind S1 of te - 1: nothing is appended to it any more)
     auto chunk_flush = [&](const int te) __attribute__((always_inline)) {
-        const int k = te & 127;
-        int id, meta;
-        open_get(k, id, meta);
-        if (id >= 0 && (meta & 0xFFFF) == (te & 0xFFFF)) {
-            chunk_close(id, te, meta >> 16);
-            open_set(k, -1, 0);
+        const int k = te & 255;
+        const int old = __builtin_amdgcn_readfirstlane(otab[k]);
+        if (old >> 8) {
+            chunk_close((old >> 8) - 1, te, old & 255);
+            if (lane == 0) otab[k] = 0;
         }
     };
-    // was UE i (bucket p) given an UL grant in one of the subframes [s0, s1] (s1 - s0 < 16, s1 at most 15 subframes old)?  The subframe, or -1.
-    auto granted_at = [&](const int i, const int p, const int s0, const int s1) -> int {
-        // the ring's bits that stand for the subframes [max(s0, 0), s1] — n of them, from bit (lo & 15) on, wrapping — in one expression: the scalar side pays for
-        // every loop iteration and every exec-masked block of this kernel (profiles/r04_grid.md), and a grant inside a UE's own window is the rare case
+    // Grant notes.  The ring's bits that stand for the subframes [max(s0, 0), s1] (s1 - s0 < 16, s1 at most 15 subframes old) — n of them, from bit (lo & 15) on,
+    // wrapping — and of those the ones bucket p has a note in: one expression, no loop (a grant inside a UE's own window is the rare case)
+    auto grant_bits = [&](const int p, const int s0, const int s1) __attribute__((always_inline)) -> unsigned {
         const int lo = max(s0, 0), n = s1 - lo + 1;
         const unsigned ones = n > 0 ? (n >= 16 ? 0xFFFFu : (1u << n) - 1u) : 0u, sh = (unsigned)lo & 15u;
-        unsigned cand = bmk[p] & (((ones << sh) | ((ones << sh) >> 16)) & 0xFFFFu);
+        return bmk[p] & (((ones << sh) | ((ones << sh) >> 16)) & 0xFFFFu);
+    };
+    // ... and which of them (cand) is UE i's: the subframe of its UL grant, or -1
+    auto grant_search = [&](unsigned cand, const int i, const int p, const int s0) __attribute__((always_inline)) -> int {
+        const int lo = max(s0, 0);
         int found = -1;
         while (cand) {
             const int b_ = 31 - __clz((int)cand), s = lo + ((b_ - lo) & 15);
@@ -309,6 +308,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         }
         return found;
     };
+    auto granted_at = [&](const int i, const int p, const int s0, const int s1) -> int { return grant_search(grant_bits(p, s0, s1), i, p, s0); };
 
     for (int t = 0; t < stop && status == PRACH_OK; t++) {
         steps++;
@@ -328,7 +328,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         int *const fcallB = BI(bl::FCALL) + (parity ^ 1) * NPB, *const lcallB = BI(bl::LCALL) + (parity ^ 1) * NPB;
         const int slot = (int)((unsigned)t & calmask);                       // this subframe's lists
         int *const histx = hr + (t & (HRING - 1)) * NPB, *const mlocx = mr + (t & (HRING - 1)) * NPB; // ... and its histogram / lowest matched index << 6 | window left
-        const int nch = nchk[slot], nj = jcnt[slot];                         // complete: every chunk was entered, every join listed in an earlier subframe
+        const int nch = nchk[slot], njall = jcnt[slot];                      // complete: every chunk was entered, every join listed in an earlier subframe
+        if (njall > calcap) scal[B_OVF] = 1;                                 // (this subframe's join list was too short: the trial leaves behind S2)
+        const int nj = min(njall, calcap);
         const int narr = activeCheck - prevAC;                               // this access slot's arrivals (Beta.c:136-146) are events too: batches behind the chunks
         const int nb = nch + ((narr + 63) >> 6);
         const PRACH_G int *const clist = ctab + (size_t)slot * (size_t)tcap;
@@ -380,8 +382,12 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                 R.a = ld_i4(c + lane); R.b = ld_i4(c + 64 + lane);
                 return R;
             };
-            // what follows selectPreamble / requestResourceAllocation for every event UE: bucket bookkeeping, special events for the resolver, the UE's next schedule
-            auto finish = [&](const bool v, const int i, UeState &u, ColdRegs &cold, const unsigned nd, const UeOut &o) __attribute__((always_inline)) {
+            // What follows selectPreamble / requestResourceAllocation for every event UE: bucket bookkeeping, special events for the resolver, the UE's next
+            // schedule.  Straight-line code on lane masks (prach_ue_body.h, "without branches"): a lane that has nothing to add to a table or list aims at a dummy
+            // word of its own, in LDS or in the pool's last chunk / behind the join lists in global memory.
+            int *const lds = BI(0);
+            const int dmy = bl::DUMMY / 4 + lane, rowx = (t & (HRING - 1)) * NPB;
+            auto finish = [&](const lmask vm, const int i, const UeState &u, const ColdRegs &cold, const unsigned nd, const FlatOut &o) __attribute__((always_inline)) {
                 if (PRACH_B_XVALU) { // (sensitivity experiment: never changes a result)
                     int x_ = 0;
 #pragma unroll
@@ -407,84 +413,80 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     if (y_ == 0x7fffffff) scal[B_OVF] = 3;
                 }
                 // ---- bucket bookkeeping (this subframe's ring row; an event UE has nothing in the later ones: window left = 0) ----
-                // (unconditional: a lane that has nothing to add hits its own dummy word — no exec-masked blocks)
-                atomicAdd(o.member_pre ? &histx[o.oldp] : &dummy[lane], 1);
-                atomicMin(u.pend == PEND_STAY ? &mlocx[o.oldp] : &dummy[lane], i << 6);
-                atomicMin(o.evtype == UEV_CALLER ? &mlocx[o.evp] : &dummy[lane], i << 6);
+                const int oldq = o.oldp & 63;
+                atomicAdd(&lds[lsel(o.member_pre, bl::HR / 4 + rowx + oldq, dmy)], 1);
+                atomicMin(&lds[lsel(lm(u.pend == PEND_STAY), bl::MR / 4 + rowx + oldq, dmy)], i << 6);
+                atomicMin(&lds[lsel(lm(o.evtype == UEV_CALLER), bl::MR / 4 + rowx + (o.evp & 63), dmy)], i << 6);
                 {
                     // (an early leaver matters only below its bucket's lowest caller, Beta.c:321-330: the lowest matched index only falls during the subframe, so a UE
                     //  at or above what it is NOW — this wavefront's joins are all in, the others' nearly — can be dropped here; the rest is looked at again behind S1)
-                    const bool cand_ = o.eclass && i < (mlocx[o.oldp] >> 6);
-                    const unsigned long long em = __ballot(o.evtype != UEV_NONE), cm = __ballot(cand_);
-                    if (em | cm) {
-                        int b_ev = 0, b_cd = 0;
-                        if (lane == 0) {
-                            if (em) b_ev = atomicAdd(&scal[B_NEV + parity], __popcll(em));
-                            if (cm) b_cd = atomicAdd(&scal[B_NCAND + parity], __popcll(cm));
-                        }
-                        b_ev = __builtin_amdgcn_readfirstlane(b_ev); b_cd = __builtin_amdgcn_readfirstlane(b_cd);
-                        if (o.evtype != UEV_NONE) {
-                            const int es = b_ev + __popcll(em & lanemask_lt(lane));
-                            ev_set(es, i, ue_event_info(o));
-                        }
-                        if (cand_) {
-                            const int cs = b_cd + __popcll(cm & lanemask_lt(lane)), cv = i | (o.oldp << 20);
-                            if (cs < CCAP) candl[cs] = cv; else ((PRACH_G int *)rare()->qov)[cs - CCAP] = cv;
+                    const lmask isev = lm(o.evtype != UEV_NONE), cand = o.eclass & lm(i < (lds[bl::MR / 4 + rowx + oldq] >> 6));
+                    if (__any((isev | cand) != 0)) { // (wave-uniform) every lane takes its own slot of the resolver's event list / of the candidate list
+                        const int es = atomicAdd(&lds[lsel(isev, bl::SCAL / 4 + B_NEV + parity, dmy)], 1);
+                        const int cs = atomicAdd(&lds[lsel(cand, bl::SCAL / 4 + B_NCAND + parity, dmy)], 1);
+                        const lmask evl = isev & lm(es < BEV), cdl = cand & lm(cs < CCAP);
+                        const int info = flat_event_info(o), cv = i | (o.oldp << 20);
+                        BI2(0)[lsel(evl, bl::GEV / 8 + es, bl::DUMMY2 / 8 + lane)] = make_int2(i, info);
+                        lds[lsel(cdl, bl::CANDL / 4 + cs, dmy)] = cv;
+                        const lmask evg = isev & ~evl, cdg = cand & ~cdl;
+                        if (__any((evg | cdg) != 0)) { // the lists' parts in global memory (event storms of extreme parameter sets)
+                            if (evg) store_i2(&evov[es - BEV], i, info);
+                            if (cdg) ((PRACH_G int *)rare()->qov)[cs - CCAP] = cv;
                         }
                     }
                 }
                 // the UE's schedule from here (prach_ue_body.h): matched in [tj, tj + dur), its next event at tj + dur
-                unsigned word = PW_IDLE;
-                if (v) word = pw_schedule(u, t, K.maxRar);
+                const unsigned word = o.word;
                 const unsigned tjn = word & 0xFFFFu, durn = (word >> 16) & 0x3Fu;
-                const bool sched_ = v && tjn != 0xFFFFu; // (0xFFFF: finished for good, or a txTime that never comes — Beta.c:167: the record goes home)
-                const int te = (int)(tjn + durn);        // the subframe of its next event
-                int jp = 0;
+                const lmask sched = vm & lm(tjn != 0xFFFFu); // (0xFFFF: finished for good, or a txTime that never comes — Beta.c:167: the record goes home)
+                const int te = (int)(tjn + durn);             // the subframe of its next event
+                const lmask joins = sched & lm(durn > 0u);
                 const int js = (int)(tjn & calmask);
-                if (sched_ && durn > 0u) jp = atomicAdd(&jcnt[js], 1);
-                // where the record goes: this wavefront's open chunk of subframe te (one round per distinct te of the batch: txTime is aligned to the access slots)
-                int cid = 0, cpos = 0;
+                const int jp = atomicAdd(&lds[lsel(joins, bl::JCNT / 4 + js, dmy)], 1);
+                // where the record goes: its place in this wavefront's open chunk of subframe te, by one atomic add on the chunk's word
+                const int old = atomicAdd(&lds[lsel(sched, bl::OPENT / 4 + w * 256 + (te & 255), dmy)], 1);
+                int cpos = old & 255, cid = (old >> 8) - 1;
                 {
-                    unsigned long long todo = __ballot(sched_);
-                    while (todo) {
-                        const int te0 = __builtin_amdgcn_readlane(te, __ffsll((long long)todo) - 1);
-                        const unsigned long long mm = __ballot(sched_ && te == te0);
-                        const int c = __popcll(mm), k = te0 & 127;
-                        int id, meta;
-                        open_get(k, id, meta);
-                        int fill = meta >> 16;
-                        if (id >= 0 && (meta & 0xFFFF) != (te0 & 0xFFFF)) { chunk_close(id, meta & 0xFFFF, fill); id = -1; } // (another subframe sits at this table position: it goes to its list as it is)
-                        if (id < 0) { id = chunk_alloc(); fill = 0; }
-                        const int room = 64 - fill;
-                        int id2 = -1;
-                        if (c > room) id2 = chunk_alloc();
-                        {
-                            const bool mine = (mm >> lane) & 1ull;
-                            const int rank = __popcll(mm & lanemask_lt(lane));
-                            cid = mine ? (rank < room ? id : id2) : cid;
-                            cpos = mine ? (rank < room ? fill + rank : rank - room) : cpos;
+                    // ... and the wave-uniform rest: a subframe without an open chunk (its lanes counted from 0) gets one, a chunk that this batch filled up joins its
+                    // subframe's list and the lanes beyond it start the next one — about one chunk per batch
+                    unsigned long long bad = __ballot((sched & (lm(cid < 0) | lm(cpos >= 64))) != 0);
+                    while (bad) {
+                        const int te0 = __builtin_amdgcn_readlane(te, __ffsll((long long)bad) - 1), k = te0 & 255;
+                        const int now = __builtin_amdgcn_readfirstlane(otab[k]);
+                        const int tot = now & 255, id0p = now >> 8;
+                        const lmask mine = sched & lm(te == te0);
+                        int idn, left;
+                        if (id0p == 0) { idn = chunk_alloc(); left = tot; cid = lsel(mine, idn, cid); }
+                        else {
+                            chunk_close(id0p - 1, te0, 64);
+                            idn = chunk_alloc(); left = tot - 64;
+                            const lmask over = mine & lm(cpos >= 64);
+                            cid = lsel(over, idn, cid); cpos -= 64 & over;
                         }
-                        if (c >= room) { chunk_close(id, te0, 64); id = id2; fill = c - room; } // (id2 = -1, fill = 0 when it is exactly full)
-                        else fill += c;
-                        open_set(k, id, (te0 & 0xFFFF) | (fill << 16));
-                        todo &= ~mm;
+                        if (lane == 0) otab[k] = ((idn + 1) << 8) | left;
+                        bad &= ~__ballot(mine != 0);
                     }
                 }
                 pipe_sync(); // the next batch's records and the entry behind them have arrived: from here on only stores are issued
-                if (sched_) {
-                    PRACH_G v4i_t *const c = chunks + (size_t)cid * CHUNK + cpos;
-                    st_i4(c, pack(u)); st_i4(c + 64, cold_pack(nd, durn, cold, i));
-                    if (durn > 0u) {
-                        if (jp < vcalcap) vjcal[(size_t)js * (size_t)vcalcap + (size_t)jp] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
-                        else scal[B_OVF] = 1;
+                {
+                    // (a lane without a record to pass on writes into the pool's last chunk, which is never handed out: chunk_alloc)
+                    PRACH_G v4i_t *const c = chunks + (size_t)(unsigned)lsel(sched, cid * CHUNK + cpos, vtrash + lane);
+                    const int4 B = cold_pack(nd, durn, cold, lsel(sched, i, (int)word));
+                    st_i4(c, pack(u)); st_i4(c + 64, B);
+                    // (an entry beyond the list's capacity lands on its last one; the list's count says so when its subframe comes: the loop's head)
+                    vjcal[(size_t)(unsigned)lsel(joins, js * vcalcap + min(jp, vcalcap - 1), vjtrash + lane)] = (int)((unsigned)i | (((word >> 24) & 0x3Fu) << 20) | (durn << 26));
+                    const lmask home = vm & ~sched; // finished for good (or never to be looked at again): once per UE
+                    if (__any(home != 0)) {
+                        if (home) {
+                            PRACH_G v4i_t *const h = (PRACH_G v4i_t *)rare()->rec32 + 2 * (size_t)i;
+                            st_i4(h, pack(u)); st_i4(h + 1, B);
+                        }
                     }
-                } else if (v) { // home: finished for good (or never to be looked at again)
-                    PRACH_G v4i_t *const home = (PRACH_G v4i_t *)rare()->rec32 + 2 * (size_t)i;
-                    st_i4(home, pack(u)); st_i4(home + 1, cold_pack(nd, 0u, cold, (int)word));
                 }
             };
-            // MODE 0: Philox, everything in one pass.  MODE 1 (GLIBC): the count pass — nothing is stored but the calling lanes.  MODE 2 (GLIBC): the full
-            // body with the draws at their stream positions (sbase: position of the subframe's first call of the UE loop).
+            const lmask wn = withnoma ? -1 : 0, rc_slot = (K.aT > 1 && tmod == 1) ? -1 : 0;
+            // MODE 0: Philox, everything in one pass, in the branch-free form.  MODE 1 (GLIBC): the count pass — nothing is stored but the calling lanes.  MODE 2
+            // (GLIBC): the full body (branched form) with the draws at their stream positions (sbase: position of the subframe's first call of the UE loop).
             auto body_pass = [&](auto MODE_, const unsigned long long sbase) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(MODE_)::value;
                 int d_c = desc_of(w), d_n = desc_of(w + NWB);
@@ -498,41 +500,72 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     if (!arrival && MODE != 1) chunk_free(dcu & 0xFFFFFF); // its records are in registers: the chunk can be filled again (by this wavefront, below)
                     // (the next batch moves into place at the END of this one, behind pipe_sync: a register move of a value still in flight would wait for it here)
                     auto rotate = [&]() __attribute__((always_inline)) { d_c = d_n; d_n = pd_n2; R_c = pR_n; };
-                    bool v = arrival ? prevAC + (b - nch) * 64 + lane < activeCheck : lane < (dcu >> 24);
-                    if (!v || arrival) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
-                    const int i = arrival ? prevAC + (b - nch) * 64 + lane : (R.b.w & 0xFFFFF);
-                    UeState u = unpack(R.a);
-                    ColdRegs cold = cold_unpack(R.b);
-                    unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
-                    const int sdur = (int)((unsigned)R.b.x >> 24);
-                    // an UL grant noted since the UE was scheduled (Beta.c:338-343) is applied as if the UE had been looked at one subframe after it: nothing else
-                    // happens to a granted UE before its Msg3, ten subframes later
-                    int tcu = t;
-                    bool granted = false;
-                    if (v && !arrival && u.act == ACT_M1 && u.pre != 0) {
-                        const int gs = granted_at(i, u.pre - 1, t - sdur - 1, t - 1);
-                        if (gs >= 0) { granted = true; tcu = gs + 1; }
-                    }
-                    if (v && !arrival) pw_catch_up(u, pw_make(t - sdur, sdur, 0), granted, i, tcu, K.fmA, tab);
-                    if (v && arrival) { // arrival (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
-                        ue_activate(u, i, t, cold);
-                        if (withnoma) nd = 2;
-                        // the reference's stream: the UE's sector is fixed by the first of its two activation calls (WithNOMA:393-410), which sit at the head of this
-                        // subframe's calls in index order (read in the select pass: the window has been checked) — kept per UE for the grant phase (PD->sector)
-                        if (GLIBC && sectors && MODE == 2) sect_arr[i] = sector_of_draw(stream[base + 2ull * (unsigned long long)(i - prevAC)]);
-                    }
-                    const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
-                    const int g_ = i >> 6, ln = i & 63;
-                    if (MODE == 1) {
-                        if (v && pl.need >= 1) {
-                            atomicOr(&gm[4 * g_ + (ln >> 5)], 1u << (ln & 31));
-                            if (pl.need == 2) atomicOr(&gm[4 * g_ + 2 + (ln >> 5)], 1u << (ln & 31));
+                    const int ia = prevAC + (b - nch) * 64 + lane; // (arrival batches: Beta.c:136-146 in index order)
+                    if constexpr (MODE == 0) {
+                        const lmask vm = arrival ? lm(ia < activeCheck) : lm(lane < (dcu >> 24));
+                        R.a.w &= vm; // (a lane without a record: inactive, nothing pending — it takes no branch of the state machine and aims at the dummies)
+                        UeState u = unpack(R.a);
+                        ColdRegs cold = cold_unpack(R.b);
+                        unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
+                        int i = R.b.w & 0xFFFFF;
+                        if (arrival) { // ue_activate (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
+                            i = ia;
+                            u.tx = lsel(vm, t + 1, -1); u.tb = t; u.bo = 0; u.act = ACT_M1 & vm; u.conn = 0; u.pre = 0; u.rar = 0; u.mrc = 0; u.pend = PEND_NONE;
+                            cold.ptc = 0; cold.ftt = t + 1; cold.stt = 0; cold.fcnt = 0;
+                            nd = withnoma ? 2u : 0u;
+                        } else {
+                            // an UL grant noted since the UE was scheduled (Beta.c:338-343) is applied as if the UE had been looked at one subframe after it: nothing
+                            // else happens to a granted UE before its Msg3, ten subframes later
+                            const int sdur = (int)((unsigned)R.b.x >> 24), p_ = (u.pre - 1) & 63;
+                            const unsigned gb = grant_bits(p_, t - sdur - 1, t - 1) & (unsigned)(lm(u.act == ACT_M1) & ~lm(u.pre == 0));
+                            const int gs = grant_search(gb, i, p_, t - sdur - 1);
+                            const lmask granted = lm(gs >= 0);
+                            flat_catch_up(u, sdur, granted, i, t, lsel(granted, gs + 1, t), K.fmA, tab);
                         }
+                        const FlatPlan pl = flat_plan(u, t, K.maxRar, K.maxMsg2);
+                        int d1 = 0, d2 = 0;
+                        if (__any(pl.need != 0)) {
+                            d1 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd, (unsigned)vnUE, (unsigned)vvariant);
+                            if (__any(pl.need > 1)) d2 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd + 1u, (unsigned)vnUE, (unsigned)vvariant);
+                            nd += (unsigned)pl.need;
+                        }
+                        FlatOut o = flat_select(u, cold, pl, d1, d2, t, rc_slot, K, wn, c_succ, c_contf);
+                        o.word = (unsigned)lsel(vm, (int)flat_schedule(u, t, K.maxRar), (int)PW_IDLE);
+                        finish(vm, i, u, cold, nd, o);
                         rotate();
-                        continue;
-                    }
-                    int d1 = 0, d2 = 0;
-                    if (MODE == 2) {
+                    } else {
+                        bool v = arrival ? ia < activeCheck : lane < (dcu >> 24);
+                        if (!v || arrival) { R.a = make_int4(-1, 0, 0, 0); R.b = make_int4(0, 0, 0, 0); }
+                        const int i = arrival ? ia : (R.b.w & 0xFFFFF);
+                        UeState u = unpack(R.a);
+                        ColdRegs cold = cold_unpack(R.b);
+                        unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
+                        const int sdur = (int)((unsigned)R.b.x >> 24);
+                        int tcu = t;
+                        bool granted = false;
+                        if (v && !arrival && u.act == ACT_M1 && u.pre != 0) {
+                            const int gs = granted_at(i, u.pre - 1, t - sdur - 1, t - 1);
+                            if (gs >= 0) { granted = true; tcu = gs + 1; }
+                        }
+                        if (v && !arrival) pw_catch_up(u, pw_make(t - sdur, sdur, 0), granted, i, tcu, K.fmA, tab);
+                        if (v && arrival) {
+                            ue_activate(u, i, t, cold);
+                            if (withnoma) nd = 2;
+                            // the reference's stream: the UE's sector is fixed by the first of its two activation calls (WithNOMA:393-410), which sit at the head of this
+                            // subframe's calls in index order (read in the select pass: the window has been checked) — kept per UE for the grant phase (PD->sector)
+                            if (sectors && MODE == 2) sect_arr[i] = sector_of_draw(stream[base + 2ull * (unsigned long long)(i - prevAC)]);
+                        }
+                        const UePlan pl = ue_plan(u, t, K.maxRar, K.maxMsg2);
+                        const int g_ = i >> 6, ln = i & 63;
+                        if (MODE == 1) {
+                            if (v && pl.need >= 1) {
+                                atomicOr(&gm[4 * g_ + (ln >> 5)], 1u << (ln & 31));
+                                if (pl.need == 2) atomicOr(&gm[4 * g_ + 2 + (ln >> 5)], 1u << (ln & 31));
+                            }
+                            rotate();
+                            continue;
+                        }
+                        int d1 = 0, d2 = 0;
                         if (v && pl.need > 0) { // the UE's position inside its group from the two lane masks
                             const unsigned lo_ = ln < 32 ? (1u << ln) - 1u : 0xffffffffu, hi_ = ln < 32 ? 0u : (1u << (ln - 32)) - 1u;
                             const int before = __popc(gm[4 * g_] & lo_) + __popc(gm[4 * g_ + 1] & hi_) + __popc(gm[4 * g_ + 2] & lo_) + __popc(gm[4 * g_ + 3] & hi_);
@@ -540,14 +573,13 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                             d1 = stream[o_];
                             if (pl.need > 1) d2 = stream[o_ + 1];
                         }
-                    } else if (__any(pl.need > 0)) {
-                        d1 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd, (unsigned)vnUE, (unsigned)vvariant);
-                        if (__any(pl.need > 1)) d2 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd + 1u, (unsigned)vnUE, (unsigned)vvariant);
-                        nd += (unsigned)pl.need;
+                        const UeOut uo = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
+                        FlatOut o;
+                        o.evtype = uo.evtype; o.evp = uo.evp; o.evq = uo.evq; o.oldp = uo.oldp; o.member_pre = lm(uo.member_pre); o.eclass = lm(uo.eclass);
+                        o.word = v ? pw_schedule(u, t, K.maxRar) : PW_IDLE;
+                        finish(lm(v), i, u, cold, nd, o);
+                        rotate();
                     }
-                    const UeOut o = ue_select(u, pl, d1, d2, i, t, tmod, K, cold, c_succ, c_contf);
-                    finish(v, i, u, cold, nd, o);
-                    rotate();
                 }
             };
             if (!GLIBC) body_pass(std::integral_constant<int, 0>{}, 0ull);
@@ -909,11 +941,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     // the event body would have (pw_catch_up).  Then end-of-trial sums (Beta.c:185-197) and the logged fields (Beta.c:501-508) of every UE from its home record.
     const int tend = tlast + 1;
     if (status == PRACH_OK && tlast >= 0) {
-#pragma nounroll
-        for (int k = 0; k < 128; k++) { // every open chunk of this wavefront joins its subframe's list
-            int id, meta;
-            open_get(k, id, meta);
-            if (id >= 0) chunk_close(id, meta & 0xFFFF, meta >> 16);
+        for (int k = lane; k < 256; k += 64) { // every open chunk of this wavefront joins its subframe's list (position k stands for the subframe in (tlast + 1, tlast + 256] that is k mod 256)
+            const int old = otab[k];
+            if (old >> 8) chunk_enter((old >> 8) - 1, tend + (int)(((unsigned)k - (unsigned)tend) & 255u), old & 255);
         }
         __syncthreads();
         const CallTables tab{BI(bl::FCALL) + (tlast & 1) * NPB, BI(bl::LCALL) + (tlast & 1) * NPB};

@@ -167,7 +167,7 @@ LaunchLayout layout_launch(const prach_cfg *cfgs, const int *idx, int m, prach_u
             if (full_calendars) { T.calcap = (int)n + 64; T.npool *= 2; }
             T.tcap = (int)((n + 63) / 64) + 256;
             T.rec32 = take(32 * n); T.chunks = take((size_t)batch_chunk_bytes() * (size_t)T.npool); T.ctab = take(4 * (size_t)T.calslots * (size_t)T.tcap);
-            T.cpool = take(8 * (size_t)T.npool); T.jcal = take(4 * (size_t)T.calslots * (size_t)T.calcap);
+            T.cpool = take(8 * (size_t)T.npool); T.jcal = take(4 * ((size_t)T.calslots * (size_t)T.calcap + 64)); // (+ 64 words: where lanes without a join entry store, prach_batch.hip)
             T.qov = take(4 * n); T.evov = take(16 * n);
         } else {
             T.rec = take(16 * n);

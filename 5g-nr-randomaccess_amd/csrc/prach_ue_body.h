@@ -245,6 +245,136 @@ __device__ __forceinline__ unsigned pw_schedule(UeState &u, const int t, const i
     return pw_make(u.tx, max(0, maxRar - 1 - u.rar), u.pre - 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// THE SAME STATE MACHINE WITHOUT BRANCHES (prach_batch.hip's event body with Philox draws).
+// pw_catch_up / ue_plan / ue_select / pw_schedule restated case by case on per-lane masks (all ones or zero in a vector register, opaque to the
+// optimiser) and bit selects: every lane computes every case's new field values and selects.  A wavefront of event UEs is a mix of all cases, so
+// the branched form runs every block anyway, each behind its own exec-mask bookkeeping (s_and_saveexec / s_cbranch_execz / s_or) with the
+// conditions' boolean algebra in scalar registers — and the ONE scalar unit a CU's four SIMDs share is what bounds the batched kernel
+// (profiles/r04_grid.md, section 5), while its vector ALUs have room.  Case by case the lines below cite the branched form above, which stays the
+// form every other kernel (and the reference-stream instantiation of the batched one) runs: the two are compared through the oracle by every
+// batched-kernel test (tests/test_gpu_parity.py, scripts/gpu_batch_check.sh).
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef int lmask;
+__device__ __forceinline__ lmask lm(const bool c) { int m = c ? -1 : 0; asm("" : "+v"(m)); return m; } // v_cmp + v_cndmask: no scalar instruction
+__device__ __forceinline__ int lsel(const lmask m, const int a, const int b) { return (a & m) | (b & ~m); } // v_bfi_b32
+__device__ __forceinline__ int fastmod_flat(const int x, const FastMod f) { // = fastmod
+    const unsigned q = __umulhi((unsigned)x, f.M);
+    const unsigned r = (unsigned)x - q * f.d;
+    return (int)min(r, r - f.d) & ~lm(f.d == 1u); // (r - d wraps above r when r < d)
+}
+__device__ __forceinline__ int slot_align_flat(const int sub, const FastMod aT) { // = slot_align_fm: m == 0: sub + 1, m == 1: sub, else sub + (aT - m + 1)
+    const int m = fastmod_flat(sub, aT);
+    return sub + ((int)aT.d + 1 - m) - ((int)aT.d & lm(m < 2));
+}
+
+// pw_catch_up: the record as the event body left it (scheduled with a window of sdur subframes ending at t) brought to the start of subframe tcu
+// (t, or the subframe after the UL grant noted for it)
+template <class TAB>
+__device__ __forceinline__ void flat_catch_up(UeState &u, const int sdur, const lmask granted, const int i, const int t, const int tcu, const FastMod fmA, const TAB &tab) {
+    const int tp = tcu - 1;
+    const lmask mreset = lm(u.pend == PEND_RESET), mpass = lm(u.pend == PEND_PASSIVE), mrj = lm(u.pend == PEND_RJOIN);
+    const int fc = tab.fcall(lsel(mreset, u.bo, u.pre - 1) & 63), lc = tab.lcall((u.pre - 1) & 63); // (every lane reads: the tables are LDS)
+    const int x = slot_align_flat(tp + (1 & lm(fc < i)) + u.tx, fmA);   // PEND_RESET: the stale txTime of Beta.c:266 (ue_apply)
+    const lmask xeq = lm(x == tp);
+    const lmask bump = (mpass & lm(fc != INT_MAX)) | (mrj & lm(lc > i)); // PEND_PASSIVE / PEND_RJOIN (ue_apply)
+    const int tx = lsel(mreset, lsel(xeq, tp + 1, x), lsel(bump, tp + 1, u.tx));
+    const int bo = lsel(mreset, x & ~xeq, u.bo);
+    u.tx = lsel(granted, tp + 11, tx);                                   // Beta.c:338-343
+    u.bo = bo & ~(granted & mreset);
+    u.act = lsel(granted, ACT_M3, u.act);
+    u.conn &= ~granted;
+    u.pend = PEND_NONE;
+    const lmask mw = lm(sdur > 0) & lm(tcu > t - sdur);                  // the subframes it was matched in since it was scheduled
+    u.rar += (tcu - (t - sdur)) & mw;
+    u.tx = lsel(mw & ~granted, tcu, u.tx);
+}
+
+struct FlatPlan { lmask isM1, pre0, firstsel, backoff, reset, retx, stay, m3first, m3to; int need; };
+__device__ __forceinline__ FlatPlan flat_plan(const UeState &u, const int t, const int maxRar, const int maxMsg2) { // = ue_plan
+    FlatPlan p;
+    p.isM1 = lm(u.act == ACT_M1); p.pre0 = lm(u.pre == 0);
+    const lmask inbo = lm(u.bo > t); // now_backoff(bo, t) > 0 (t >= 0)
+    const lmask hasp = p.isM1 & ~p.pre0;
+    p.firstsel = p.isM1 & p.pre0;
+    p.backoff = hasp & inbo;
+    const lmask contend = hasp & ~inbo;
+    const lmask expire = contend & lm(u.rar + 1 >= maxRar);
+    p.reset = expire & lm(u.mrc >= maxMsg2);
+    p.retx = expire & ~p.reset;
+    p.stay = contend & ~expire;
+    const lmask m3due = lm(u.act == ACT_M3) & lm(u.tx == t), c0 = lm(u.conn == 0);
+    p.m3first = m3due & c0; p.m3to = m3due & ~c0;
+    p.need = (1 & (p.firstsel | p.retx | p.m3first)) | (2 & (p.reset | p.m3to));
+    return p;
+}
+
+// what finish() of prach_batch.hip needs of a UE's subframe
+struct FlatOut { int evtype, evp, evq, oldp; lmask member_pre, eclass; unsigned word; };
+// = ue_select (ColdRegs only: the cold fields ride in the record)
+__device__ __forceinline__ FlatOut flat_select(UeState &u, ColdRegs &cold, const FlatPlan &p, const int d1, const int d2, const int t, const lmask rc_slot /* aT > 1 && t mod aT == 1 */,
+                                               const UeK &K, const lmask withnoma, int &c_succ, int &c_contf) {
+    FlatOut o;
+    const int oldp = u.pre - 1;
+    const lmask txnow = lm(u.tx == t);
+    const lmask member = p.isM1 & txnow & ~p.pre0;
+    const int fP1 = fastmod_flat(d1, K.fmP), fB1 = fastmod_flat(d1, K.fmB), fB2 = fastmod_flat(d2, K.fmB), fP2 = fastmod_flat(d2, K.fmP);
+    // the one new txTime a subframe can bring: reset cycle outside the bucket (Beta.c:266-279), retransmission (Beta.c:296-305), Msg3 timeout (Beta.c:389-399)
+    const lmask rsm = p.reset & member, rsn = p.reset & ~member;
+    const lmask S = rsn | p.retx | p.m3to;
+    FastMod fm;
+    fm.d = (unsigned)lsel(p.m3to, (int)K.fm5.d, (int)K.fmA.d); fm.M = (unsigned)lsel(p.m3to, (int)K.fm5.M, (int)K.fmA.M);
+    const int sa = slot_align_flat(lsel(p.retx, t, u.tx) + lsel(p.reset, fB2, fB1), fm);
+    const lmask sanow = S & lm(sa == t);
+    const float pf = (float)d1 / (float)2147483647;                      // Beta.c:374 ((float)RAND_MAX == 2^31)
+    const lmask ok = p.m3first & lm((double)pf > 0.1), nok = p.m3first & ~ok;
+    const lmask fs = p.firstsel;
+    const lmask callF = fs & txnow, callS = (rsn | p.retx) & sanow, rj = p.m3to & sanow;
+    const lmask rc = rsm & lm(fB2 == 0) & rc_slot;                       // reset cycle that may re-join its slot (ue_select: UEV_RESETCAND)
+    o.evtype = (UEV_CALLER & (callF | callS)) | (UEV_RESETCAND & rc) | (UEV_RJOIN & rj);
+    o.evp = (fP1 & (callF | (rsn & sanow) | rc)) | (oldp & (p.retx & sanow)) | (fP2 & rj);
+    o.evq = oldp & rc;
+    o.oldp = oldp; o.member_pre = member;
+    o.eclass = rsm | (p.retx & ~sanow & member);
+    u.pend = (PEND_CALLER & (callF | callS)) | (PEND_RESET & rsm) | (PEND_RJOIN & rj) | (lsel(withnoma, PEND_STAY, PEND_PASSIVE) & (p.backoff & member)) | (PEND_STAY & (p.stay & member));
+    const lmask z = fs | p.reset | p.m3to;
+    u.rar = (u.rar + (1 & p.stay)) & ~(z | p.retx);                      // Beta.c:245, then the resets
+    u.mrc = (u.mrc + (1 & p.retx)) & ~z;
+    u.pre = lsel(fs | p.reset, fP1 + 1, lsel(p.m3to, fP2 + 1, u.pre));
+    const int enc = lsel(lm(sa > t), sa, sa - t);                        // enc_backoff(sa - t, t)
+    u.bo = lsel(rsm, oldp, lsel(S, enc, u.bo & ~fs));
+    u.tx = lsel(rsm, fB2, lsel(S, sa, u.tx + (48 & nok)));
+    u.tb = lsel(p.reset | p.m3to, t, lsel(ok, (t - u.tb) + 6, u.tb));
+    u.conn = lsel(p.m3first, lsel(ok, 1, 2), u.conn & ~p.m3to);
+    u.act = lsel(ok, ACT_DONE, lsel(p.m3to, ACT_M1, u.act));
+    cold.ptc = lsel(fs | p.reset, 1, cold.ptc + (1 & p.retx));
+    cold.ftt = lsel(p.reset, t + 1, cold.ftt);
+    cold.stt = lsel(p.retx, sa, cold.stt);
+    cold.fcnt = (cold.fcnt + (1 & withnoma & (p.reset | p.m3to))) & ~(withnoma & fs);
+    c_contf += 1 & ((withnoma & p.reset) | p.m3to);
+    c_succ += 1 & ok;
+    return o;
+}
+
+// = pw_schedule
+__device__ __forceinline__ unsigned flat_schedule(UeState &u, const int t, const int maxRar) {
+    const lmask done = lm(u.act == ACT_DONE), m3 = lm(u.act == ACT_M3), m1 = ~(done | m3);
+    const lmask px = lm((unsigned)(u.pend - PEND_RESET) < 3u), pcs = lm((unsigned)(u.pend - PEND_STAY) < 2u);
+    u.tx = lsel(m1 & pcs, t + 1, u.tx);
+    const lmask later = lm(u.tx > t);
+    const lmask clean = later & lsel(lm(u.bo > 0), lm(u.bo == u.tx), lm(u.tx == t + 1));
+    const lmask win = m1 & ~px & clean;
+    const int tj = lsel(done, 0xFFFF, lsel(m3, lsel(later, u.tx, 0xFFFF), lsel(win, u.tx, t + 1)));
+    const int dur = max(0, maxRar - 1 - u.rar) & win;
+    const int pre = (u.pre - 1) & (m1 & ~px);
+    return ((unsigned)tj & 0xFFFFu) | ((unsigned)dur << 16) | ((unsigned)pre << 24) | (0x40000000u & (unsigned)done);
+}
+// = ue_event_info
+__device__ __forceinline__ int flat_event_info(const FlatOut &o) {
+    const int ispre = 1 & ((lm(o.evtype == UEV_CALLER) & o.member_pre & lm(o.oldp == o.evp)) | (lm(o.evtype == UEV_RESETCAND) & lm(o.evp == o.evq)));
+    return o.evtype | (ispre << 3) | (o.evp << 4) | (o.evq << 12);
+}
+
 // resolver-side info word of a special event (20 bits): type[2:0] ispre[3] bucket p[11:4] old bucket q[19:12]
 __device__ __forceinline__ int ue_event_info(const UeOut &o) {
     const int ispre = (o.evtype == UEV_CALLER) ? (o.member_pre && o.oldp == o.evp) : (o.evtype == UEV_RESETCAND ? (o.evp == o.evq) : 0);
