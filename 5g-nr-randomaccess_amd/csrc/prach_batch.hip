@@ -118,7 +118,10 @@ template <int NWB> struct BL {
     static constexpr int CANDL = JCNT + 4 * CR;            // int [CAND] early-leaver candidates: index | old bucket << 20
     static constexpr int DUMMY = CANDL + 4 * C::CAND;      // int [64] per-lane dummy words: what a lane adds to / takes the minimum of when it has nothing to contribute
     static constexpr int DUMMY2 = DUMMY + 4 * 64;          // int2 [64] the same for 8-byte entries
-    static constexpr int OPENT = DUMMY2 + 8 * 64;          // int [NWB][256] per wavefront: the open chunk of every subframe ahead, (id + 1) << 8 | records in it
+    static constexpr int DR = DUMMY2 + 8 * 64;             // int [HRING][NPB] difference ring of the histogram: + 1 in the subframe a UE's contention window opens, - 1 in the one after its last
+    static constexpr int ER = DR + 4 * HRING * NPB;        // int [HRING][NPB] per subframe a contention window ENDS in (the first one it no longer covers): the lowest index among the UEs inside such a window
+    static constexpr int RUN = ER + 4 * HRING * NPB;       // int [NPB] the differences summed up to this subframe: UEs inside their window, per bucket
+    static constexpr int OPENT = RUN + 4 * NPB;            // int [NWB][256] per wavefront: the open chunk of every subframe ahead, (id + 1) << 8 | records in it
     static constexpr int END = OPENT + 4 * 256 * NWB;
     static_assert(SIDX % 16 == 0 && HR % 16 == 0, "alignment");
 };
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     PRACH_G int *const sect_arr = (PRACH_G int *)PD->sector;     // [nUE] (PRACH_FLAG_SECTOR_GRANTS in the reference's stream only) the UE's sector
     const PRACH_G int *const sched = (const PRACH_G int *)PD->sched;
     int *const scal = BI(bl::SCAL);
+    int *const lds = BI(0); // (the whole LDS as words: tables addressed by a selected word offset, bl::X / 4 + index)
     int2 *const gev = BI2(bl::GEV);
     // the event list of a subframe: BEV entries in LDS, the rest (event storms of extreme parameter sets) in global memory — no capacity
     PRACH_G v2i_t *const evov = (PRACH_G v2i_t *)PD->evov;
@@ -193,7 +197,6 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     int *const hr = BI(bl::HR), *const mr = BI(bl::MR), *const rg = BI(bl::RG), *const rov = BI(bl::ROV);
     unsigned *const bmk = BU(bl::BM);
     int *const candl = BI(bl::CANDL);
-    int *const dummy = BI(bl::DUMMY);
     unsigned *const gm = BU(BLG::GM);  // (GLIBC only) [BGG][4]: lanes with >= 1 call (two words), lanes with 2 calls (two words)
     int *const gpre = BI(BLG::GPRE);   // (GLIBC only) [BGG]
     const PRACH_G int *const stream = (const PRACH_G int *)PD->stream;
@@ -206,13 +209,12 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     // every use) — and the scalar side is what bounds this kernel (profiles/r04_grid.md).  Held in vector registers (the wavefront has ~35 to spare at four
     // wavefronts per SIMD) they cost nothing to use: a VALU operand either way.
 #define B_TO_VGPR(x) asm volatile("" : "+v"(x))
-    unsigned vseed_lo = seed_lo, vseed_hi = seed_hi;
-    int vnUE = nUE, vvariant = variant, vcalcap = calcap, vtcap = tcap;
-    B_TO_VGPR(vseed_lo); B_TO_VGPR(vseed_hi); B_TO_VGPR(vnUE); B_TO_VGPR(vvariant); B_TO_VGPR(vcalcap); B_TO_VGPR(vtcap);
-    B_TO_VGPR(K.fmP.d); B_TO_VGPR(K.fmP.M); B_TO_VGPR(K.fmB.d); B_TO_VGPR(K.fmB.M); B_TO_VGPR(K.fmA.d); B_TO_VGPR(K.fmA.M); B_TO_VGPR(K.fm5.d); B_TO_VGPR(K.fm5.M);
+    int vcalcap = calcap;
+    B_TO_VGPR(vcalcap);
+    B_TO_VGPR(K.fmP.d); B_TO_VGPR(K.fmP.M); B_TO_VGPR(K.fmB.d); B_TO_VGPR(K.fmB.M); B_TO_VGPR(K.fmA.d); B_TO_VGPR(K.fmA.M); // (fm5: literals)
     B_TO_VGPR(K.maxMsg2);
-    PRACH_G int *vjcal = jcal, *vctab = ctab;
-    B_TO_VGPR(vjcal); B_TO_VGPR(vctab);
+    PRACH_G int *vjcal = jcal;
+    B_TO_VGPR(vjcal);
     int vtrash = (PD->nchunks - 1) * CHUNK, vjtrash = ((int)calmask + 1) * calcap; // where lanes with nothing to store aim: the pool's last chunk (never handed out), 64 words behind the join lists
     B_TO_VGPR(vtrash); B_TO_VGPR(vjtrash);
 #undef B_TO_VGPR
@@ -221,11 +223,11 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     auto rare = [&]() __attribute__((always_inline)) -> const TrialDev * { const TrialDev *q = PD; asm volatile("" : "+s"(q)); return q; };
     // calloc + initialUE (Beta.c:78-83)
     for (int i = tid; i < nUE; i += TB) { st_i4(rec32 + 2 * (size_t)i, make_int4(-1, 0, 0, 0)); st_i4(rec32 + 2 * (size_t)i + 1, make_int4(0, 0, 0, (int)PW_IDLE)); }
-    for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; rg[k] = -1; }
+    for (int k = tid; k < HRING * NPB; k += TB) { hr[k] = 0; mr[k] = INT_MAX; rg[k] = -1; BI(bl::DR)[k] = 0; BI(bl::ER)[k] = INT_MAX; }
     for (int k = tid; k < CR; k += TB) { nchk[k] = 0; jcnt[k] = 0; }
     for (int k = tid; k < 256 * NWB; k += TB) BI(bl::OPENT)[k] = 0;
     if (tid < NPB) {
-        BI(bl::TOTAL)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; BI(bl::FMINP)[tid] = INT_MAX; bmk[tid] = 0u;
+        BI(bl::TOTAL)[tid] = 0; BI(bl::RUN)[tid] = 0; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0; BI(bl::FMINP)[tid] = INT_MAX; bmk[tid] = 0u;
         BI(bl::FCALL)[tid] = INT_MAX; BI(bl::FCALL)[NPB + tid] = INT_MAX; BI(bl::LCALL)[tid] = -1; BI(bl::LCALL)[NPB + tid] = -1;
     }
     if (tid < 64) scal[tid] = 0;
@@ -273,7 +275,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     auto chunk_enter = [&](const int id, const int te, const int count) __attribute__((always_inline)) {
         const int sl = (int)((unsigned)te & calmask);
         const int seq = atomicAdd(&nchk[sl], 1);
-        if (seq < vtcap) vctab[(size_t)sl * (size_t)vtcap + (size_t)seq] = id | (count << 24);
+        const TrialDev *q = rare(); // (once per chunk: the table's address and capacity are read where they are used)
+        const int tc_ = q->tcap;
+        if (seq < tc_) ((PRACH_G int *)q->ctab)[(size_t)sl * (size_t)tc_ + (size_t)seq] = id | (count << 24);
         else scal[B_OVF] = 4;
     };
     auto chunk_close = [&](const int id, const int te, const int count) __attribute__((always_inline)) { if (lane == 0) chunk_enter(id, te, count); }; // wave-uniform
@@ -336,10 +340,17 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         const PRACH_G int *const clist = ctab + (size_t)slot * (size_t)tcap;
         BSTAMP(0); // loop head
 
-        // ================= joins: UEs whose contention window opens in this subframe enter the ring's subframes t .. t + dur - 1 =================
+        // The UEs that are inside a contention window opened EARLIER: the lowest index of every bucket among them, from the windows' end rows — a window that
+        // ends in subframe t + k still has k - 1 subframes ahead.  One wavefront (lane = bucket) seeds this subframe's row with it; joins and events lower it further.
+        for (int k = 1 + w; k <= 10; k += NWB) { // (a window ends at most maxRarWindow - 1 <= 10 subframes ahead; rows nothing ends in hold INT_MAX; one row per wavefront)
+            const int v_ = BI(bl::ER)[((t + k) & (HRING - 1)) * NPB + lane];
+            atomicMin(&lds[lsel(lm(v_ != INT_MAX), bl::MR / 4 + (t & (HRING - 1)) * NPB + lane, bl::DUMMY / 4 + lane)], (v_ << 6) | (k - 1));
+        }
+        // ================= joins: UEs whose contention window opens in this subframe enter the histogram and the lowest-index tables =================
         { // (from the last wavefront down: the first ones have the most event batches; the next batch's entries are in flight while this one's atomics are issued)
             const PRACH_G int *const jl = jcal + (size_t)slot * (size_t)calcap;
             const int qs = (NWB - 1 - w) * 64;
+            const int dmyj = bl::DUMMY / 4 + lane;
             int je_n = qs + lane < nj ? jl[qs + lane] : 0;
             for (int q0 = qs; q0 < nj; q0 += NWB * 64) {
                 const int q = q0 + lane;
@@ -347,15 +358,16 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                 je_n = q + NWB * 64 < nj ? jl[q + NWB * 64] : 0;
                 const int i = je & 0xFFFFF, p = (je >> 20) & 63;
                 int dur = (int)((unsigned)je >> 26);
-                if (q >= nj || granted_at(i, p, t - 1, t - 1) >= 0) dur = 0; // (granted in the subframe it was scheduled in: out of contention, Beta.c:338-343)
-                const int dmax = wave_max(dur);
-                // (lanes whose window is shorter — or that take no part — add 0 to / take the minimum of a per-lane dummy word: one exec-masked block less per round)
-                for (int k = 0; k < dmax; k++) {
-                    const bool in = k < dur;
-                    const int rs = ((t + k) & (HRING - 1)) * NPB + p;
-                    atomicAdd(in ? &hr[rs] : &dummy[lane], 1);
-                    atomicMin(in ? &mr[rs] : &dummy[lane], (i << 6) | (dur - 1 - k));
-                }
+                dur &= ~(lm(q >= nj) | lm(grant_search(grant_bits(p, t - 1, t - 1), i, p, t - 1) >= 0)); // (granted in the subframe it was scheduled in: out of contention, Beta.c:338-343)
+                // the histogram of the matched UEs is kept as DIFFERENCES: + 1 where the window opens, - 1 where it has closed (summed up subframe by subframe
+                // behind S1) — two atomics per window instead of one per subframe of it; a lane without a window adds to its own dummy word
+                const lmask has = lm(dur > 0);
+                atomicAdd(&lds[lsel(has, bl::DR / 4 + (t & (HRING - 1)) * NPB + p, dmyj)], 1);
+                atomicSub(&lds[lsel(has, bl::DR / 4 + ((t + dur) & (HRING - 1)) * NPB + p, dmyj)], 1);
+                // the lowest matched index: of THIS subframe (the ring's row t, as the event body's), and of the subframe the window ends in (ER: the later
+                // subframes of the window are served from there, by the seeding at every subframe's head) — no loop over the window's subframes
+                atomicMin(&lds[lsel(has, bl::MR / 4 + (t & (HRING - 1)) * NPB + p, dmyj)], (i << 6) | (dur - 1));
+                atomicMin(&lds[lsel(has, bl::ER / 4 + ((t + dur) & (HRING - 1)) * NPB + p, dmyj)], i);
             }
         }
         BSTAMP(1); // joins
@@ -385,14 +397,13 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             // What follows selectPreamble / requestResourceAllocation for every event UE: bucket bookkeeping, special events for the resolver, the UE's next
             // schedule.  Straight-line code on lane masks (prach_ue_body.h, "without branches"): a lane that has nothing to add to a table or list aims at a dummy
             // word of its own, in LDS or in the pool's last chunk / behind the join lists in global memory.
-            int *const lds = BI(0);
             const int dmy = bl::DUMMY / 4 + lane, rowx = (t & (HRING - 1)) * NPB;
             auto finish = [&](const lmask vm, const int i, const UeState &u, const ColdRegs &cold, const unsigned nd, const FlatOut &o) __attribute__((always_inline)) {
                 if (PRACH_B_XVALU) { // (sensitivity experiment: never changes a result)
                     int x_ = 0;
 #pragma unroll
                     for (int k_ = 0; k_ < PRACH_B_XVALU; k_++) x_ ^= philox_draw31(seed_lo, seed_hi, (unsigned)i, nd + 77u + (unsigned)k_, (unsigned)nUE, (unsigned)variant);
-                    if (x_ == 0x7fffffff && nd == 0xfffffffu) scal[B_OVF] = 3;
+                    if (x_ == 0x7fffffff && i == 0xffffe) scal[B_OVF] = 3; // (a condition the compiler cannot decide — `nd == 0xfffffff` it could: nd has 24 bits, and the draws were gone)
                 }
                 if (PRACH_B_XSALU) {
                     int z_ = t;
@@ -504,15 +515,18 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                     if constexpr (MODE == 0) {
                         const lmask vm = arrival ? lm(ia < activeCheck) : lm(lane < (dcu >> 24));
                         R.a.w &= vm; // (a lane without a record: inactive, nothing pending — it takes no branch of the state machine and aims at the dummies)
+                        unsigned nd = arrival ? (withnoma ? 2u : 0u) : ((unsigned)R.b.x & 0xFFFFFFu);
+                        int i = arrival ? ia : (R.b.w & 0xFFFFF);
+                        // The draws come FIRST, while only the raw record is held in registers (Philox's twenty temporaries on top of the unpacked state and the
+                        // plan's masks do not fit the wavefront's 128 registers: spilled ones are scratch loads that the in-order memory counter makes wait for the
+                        // next batch's records).  Whether any lane needs one or two is read off the packed word — never too few: a UE draws at its first selection
+                        // (arrival), when its RAR window expires (once; twice if the retransmissions are used up: Beta.c:250,282) and at Msg3 / its timeout
+                        // (Beta.c:372,384); an UL grant or a backoff found by the catch-up only takes draws away.
                         UeState u = unpack(R.a);
                         ColdRegs cold = cold_unpack(R.b);
-                        unsigned nd = (unsigned)R.b.x & 0xFFFFFFu;
-                        int i = R.b.w & 0xFFFFF;
                         if (arrival) { // ue_activate (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
-                            i = ia;
                             u.tx = lsel(vm, t + 1, -1); u.tb = t; u.bo = 0; u.act = ACT_M1 & vm; u.conn = 0; u.pre = 0; u.rar = 0; u.mrc = 0; u.pend = PEND_NONE;
                             cold.ptc = 0; cold.ftt = t + 1; cold.stt = 0; cold.fcnt = 0;
-                            nd = withnoma ? 2u : 0u;
                         } else {
                             // an UL grant noted since the UE was scheduled (Beta.c:338-343) is applied as if the UE had been looked at one subframe after it: nothing
                             // else happens to a granted UE before its Msg3, ten subframes later
@@ -525,8 +539,13 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                         const FlatPlan pl = flat_plan(u, t, K.maxRar, K.maxMsg2);
                         int d1 = 0, d2 = 0;
                         if (__any(pl.need != 0)) {
-                            d1 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd, (unsigned)vnUE, (unsigned)vvariant);
-                            if (__any(pl.need > 1)) d2 = philox_draw31(vseed_lo, vseed_hi, (unsigned)i, nd + 1u, (unsigned)vnUE, (unsigned)vvariant);
+                            // (the key and the trial's two constant counter words enter Philox through an opaque copy made HERE: left to the compiler, the twenty round
+                            //  keys and the first round's products are hoisted out of the step loop and held in 24 vector registers the whole kernel long — registers the
+                            //  body does not have: it spilled to scratch, and a scratch load makes the in-order memory counter wait for the next batch's records)
+                            unsigned k0_ = seed_lo, k1_ = seed_hi, c2_ = (unsigned)nUE, c3_ = (unsigned)variant;
+                            asm volatile("" : "+s"(k0_), "+s"(k1_), "+s"(c2_), "+s"(c3_));
+                            if (__any(pl.need > 1)) philox_draw31_x2(k0_, k1_, (unsigned)i, nd, c2_, c3_, d1, d2);
+                            else d1 = philox_draw31(k0_, k1_, (unsigned)i, nd, c2_, c3_);
                             nd += (unsigned)pl.need;
                         }
                         FlatOut o = flat_select(u, cold, pl, d1, d2, t, rc_slot, K, wn, c_succ, c_contf);
@@ -645,7 +664,9 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             if (tid < NPB) { // this workgroup's histogram / lowest callers ARE the totals (only read here: the filter above reads them too)
                 lcallB[tid] = -1; BI(bl::NLV)[tid] = 0; BI(bl::FIE)[tid] = 0;
                 const int m_ = mlocx[tid];
-                BI(bl::TOTAL)[tid] = histx[tid]; fcallA[tid] = m_ == INT_MAX ? INT_MAX : (m_ >> 6); BI(bl::FMINP)[tid] = m_;
+                const int run_ = BI(bl::RUN)[tid] + BI(bl::DR)[(t & (HRING - 1)) * NPB + tid]; // the UEs inside their window in this subframe: the differences summed up
+                BI(bl::RUN)[tid] = run_; BI(bl::DR)[(t & (HRING - 1)) * NPB + tid] = 0;        // (this row is the subframe t + HRING from here on)
+                BI(bl::TOTAL)[tid] = histx[tid] + run_; fcallA[tid] = m_ == INT_MAX ? INT_MAX : (m_ >> 6); BI(bl::FMINP)[tid] = m_;
                 // the grant notes of subframe t - 16 make room for this subframe's (no record scheduled that long ago is still on its way)
                 rg[(t & 15) * NPB + tid] = -1; bmk[tid] &= ~(1u << (t & 15));
             }
@@ -661,7 +682,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         BSTAMP(6);
         if (scal[B_OVF]) { status = PRACH_ERR_INTERNAL; why = 4 + scal[B_OVF]; time_exit = t; break; } // 5 a join list, 6 the grant notes, 8 a chunk table, 9 the chunk pool: full
         const int N = scal[B_NEV + parity];
-        if (tid < NPB) { histx[tid] = 0; mlocx[tid] = INT_MAX; } // (this ring row is the subframe t + HRING from here on: joined at t + 2 at the earliest)
+        if (tid < NPB) { histx[tid] = 0; mlocx[tid] = INT_MAX; BI(bl::ER)[(t & (HRING - 1)) * NPB + tid] = INT_MAX; } // (these ring rows are the subframe t + HRING from here on; ER's row t held the windows that ended before t)
         const int nsucc_tot = scal[B_NSUCC];
         // classify the events against the lowest DEFINITE caller of every bucket
         for (int k = tid; k < N; k += TB) {
@@ -791,11 +812,8 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             const int fm = BI(bl::FMINP)[bp];
             if ((fm >> 6) == my && fm != INT_MAX) {
                 const int rem = fm & 63;
-                for (int k = 1; k <= rem; k++) {
-                    const int rs = ((t + k) & (HRING - 1)) * NPB + bp;
-                    atomicSub(&hr[rs], 1);
-                    atomicCAS(&mr[rs], (my << 6) | (rem - k), INT_MAX);
-                }
+                if (rem > 0) { atomicSub(&BI(bl::DR)[((t + 1) & (HRING - 1)) * NPB + bp], 1); atomicAdd(&BI(bl::DR)[((t + rem + 1) & (HRING - 1)) * NPB + bp], 1); } // out of the histogram from t + 1 on
+                if (rem > 0) atomicCAS(&BI(bl::ER)[((t + rem + 1) & (HRING - 1)) * NPB + bp], my, INT_MAX); // ... and out of the lowest-index table of its window (it was alone in it)
             }
         };
         // a caller's sector: Philox — a function of the UE's own first activation draw, recomputed; the reference's stream — kept in the UE's record

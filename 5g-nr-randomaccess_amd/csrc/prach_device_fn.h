@@ -33,17 +33,35 @@ __device__ __forceinline__ int slot_align_fm(int sub, const FastMod aT) { // Bet
 __device__ __forceinline__ int now_backoff(int bo, int t) { return bo > 0 ? max(bo - t, 0) : bo; }
 __device__ __forceinline__ int enc_backoff(int X, int t) { return X > 0 ? t + X : X; }
 
+// Philox4x32-10 (the draw = word 0 of the block >> 1).  Written for gfx950's instruction set: one v_mad_u64_u32 per 32 x 32 -> 64 product (the compiler
+// emits a v_mul_hi_u32 + v_mul_lo_u32 pair for __umulhi and *), one v_bitop3_b32 per three-way xor — 6 vector instructions per round instead of 10.  The
+// batched kernel is bound by instruction issue and the multiplies are its most expensive instructions (profiles/r04_grid.md, section 5).
+__device__ __forceinline__ unsigned xor3(const unsigned a, const unsigned b, const unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ int philox_draw31(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2,
                                              unsigned c3) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = xor3((unsigned)(p1 >> 32), c1, k0), n2 = xor3((unsigned)(p0 >> 32), c3, k1);
+        c0 = n0; c1 = (unsigned)p1; c2 = n2; c3 = (unsigned)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return (int)(c0 >> 1);
+}
+// two consecutive draws of one UE (counter words c1 and c1 + 1): the round keys are computed once
+__device__ __forceinline__ void philox_draw31_x2(unsigned k0, unsigned k1, const unsigned c0_, const unsigned c1_, const unsigned c2_, const unsigned c3_, int &d1, int &d2) {
+    unsigned a0 = c0_, a1 = c1_, a2 = c2_, a3 = c3_, b0 = c0_, b1 = c1_ + 1u, b2 = c2_, b3 = c3_;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long pa0 = (unsigned long long)0xD2511F53u * a0, pa1 = (unsigned long long)0xCD9E8D57u * a2;
+        const unsigned long long pb0 = (unsigned long long)0xD2511F53u * b0, pb1 = (unsigned long long)0xCD9E8D57u * b2;
+        const unsigned na0 = xor3((unsigned)(pa1 >> 32), a1, k0), na2 = xor3((unsigned)(pa0 >> 32), a3, k1);
+        const unsigned nb0 = xor3((unsigned)(pb1 >> 32), b1, k0), nb2 = xor3((unsigned)(pb0 >> 32), b3, k1);
+        a0 = na0; a1 = (unsigned)pa1; a2 = na2; a3 = (unsigned)pa0;
+        b0 = nb0; b1 = (unsigned)pb1; b2 = nb2; b3 = (unsigned)pb0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    d1 = (int)(a0 >> 1); d2 = (int)(b0 >> 1);
 }
 
 // activateUEs (WithNOMA:393-410): theta from the first of the two activation draws fixes the UE's 60-degree sector (float arithmetic and
