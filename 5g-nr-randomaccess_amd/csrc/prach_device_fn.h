@@ -17,7 +17,7 @@ struct FastMod { unsigned d, M; };
 __device__ __forceinline__ FastMod make_fastmod(int d) {
     FastMod f;
     f.d = (unsigned)d;
-    f.M = d > 1 ? (unsigned)(0x100000000ull / (unsigned long long)d) : 0u;
+    f.M = d > 1 ? (unsigned)(0x100000000ull / (unsigned long long)d) : (d == 1 ? 0xFFFFFFFFu : 0u); // (d == 1: q = x - 1 for x > 0, so r = 1 and the correction gives 0 without a special case)
     return f;
 }
 __device__ __forceinline__ int fastmod(int x, const FastMod f) {

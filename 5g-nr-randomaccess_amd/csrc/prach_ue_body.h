@@ -261,7 +261,7 @@ __device__ __forceinline__ int lsel(const lmask m, const int a, const int b) { r
 __device__ __forceinline__ int fastmod_flat(const int x, const FastMod f) { // = fastmod
     const unsigned q = __umulhi((unsigned)x, f.M);
     const unsigned r = (unsigned)x - q * f.d;
-    return (int)min(r, r - f.d) & ~lm(f.d == 1u); // (r - d wraps above r when r < d)
+    return (int)min(r, r - f.d); // (r - d wraps above r when r < d; d == 1: make_fastmod's M makes r = 1 for x > 0)
 }
 __device__ __forceinline__ int slot_align_flat(const int sub, const FastMod aT) { // = slot_align_fm: m == 0: sub + 1, m == 1: sub, else sub + (aT - m + 1)
     const int m = fastmod_flat(sub, aT);
@@ -318,7 +318,14 @@ __device__ __forceinline__ FlatOut flat_select(UeState &u, ColdRegs &cold, const
     const int oldp = u.pre - 1;
     const lmask txnow = lm(u.tx == t);
     const lmask member = p.isM1 & txnow & ~p.pre0;
-    const int fP1 = fastmod_flat(d1, K.fmP), fB1 = fastmod_flat(d1, K.fmB), fB2 = fastmod_flat(d2, K.fmB), fP2 = fastmod_flat(d2, K.fmP);
+    // a UE reduces each draw by ONE modulus: the first by the preamble count at a first selection / reset cycle (Beta.c:231,251), by the backoff window at a
+    // retransmission / Msg3 timeout (Beta.c:296,388); the second by the backoff window in a reset cycle (Beta.c:252), by the preamble count at a Msg3 timeout (Beta.c:400)
+    const lmask pfirst = p.firstsel | p.reset;
+    FastMod f1, f2;
+    f1.d = (unsigned)lsel(pfirst, (int)K.fmP.d, (int)K.fmB.d); f1.M = (unsigned)lsel(pfirst, (int)K.fmP.M, (int)K.fmB.M);
+    f2.d = (unsigned)lsel(p.reset, (int)K.fmB.d, (int)K.fmP.d); f2.M = (unsigned)lsel(p.reset, (int)K.fmB.M, (int)K.fmP.M);
+    const int r1 = fastmod_flat(d1, f1), r2 = fastmod_flat(d2, f2);
+    const int fP1 = r1, fB1 = r1, fB2 = r2, fP2 = r2; // (each name is only used under the cases it is valid for)
     // the one new txTime a subframe can bring: reset cycle outside the bucket (Beta.c:266-279), retransmission (Beta.c:296-305), Msg3 timeout (Beta.c:389-399)
     const lmask rsm = p.reset & member, rsn = p.reset & ~member;
     const lmask S = rsn | p.retx | p.m3to;
