@@ -204,10 +204,10 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
     unsigned long long base = 0; // GLIBC: rand() calls consumed so far (relative to the stream window)
 
     const int totgroups = (nUE + 63) >> 6;
-    // The event body's constants (divisor magics, the Philox key, list capacities, the pointers of the rarely taken paths) are wave-uniform: as such they would
-    // sit in scalar registers across the whole step loop, where the budget of 102 is spent twice over (159 spilled scalars: a v_readlane / v_writelane pair around
-    // every use) — and the scalar side is what bounds this kernel (profiles/r04_grid.md).  Held in vector registers (the wavefront has ~35 to spare at four
-    // wavefronts per SIMD) they cost nothing to use: a VALU operand either way.
+    // The event body's constants (divisor magics, list capacities, the pointers the body stores through) are wave-uniform: as such they would sit in scalar
+    // registers across the whole step loop, where the budget of 102 is spent twice over (~100 spilled scalars: a v_readlane / v_writelane pair around every
+    // use) — and the kernel is bound by instruction issue (profiles/r04_grid.md).  Held in vector registers they are a plain VALU operand.  The Philox key does NOT
+    // live there: see the draws in the event body.
 #define B_TO_VGPR(x) asm volatile("" : "+v"(x))
     int vcalcap = calcap;
     B_TO_VGPR(vcalcap);

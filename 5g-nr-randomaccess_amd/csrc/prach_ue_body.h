@@ -250,10 +250,11 @@ __device__ __forceinline__ unsigned pw_schedule(UeState &u, const int t, const i
 // pw_catch_up / ue_plan / ue_select / pw_schedule restated case by case on per-lane masks (all ones or zero in a vector register, opaque to the
 // optimiser) and bit selects: every lane computes every case's new field values and selects.  A wavefront of event UEs is a mix of all cases, so
 // the branched form runs every block anyway, each behind its own exec-mask bookkeeping (s_and_saveexec / s_cbranch_execz / s_or) with the
-// conditions' boolean algebra in scalar registers — and the ONE scalar unit a CU's four SIMDs share is what bounds the batched kernel
-// (profiles/r04_grid.md, section 5), while its vector ALUs have room.  Case by case the lines below cite the branched form above, which stays the
-// form every other kernel (and the reference-stream instantiation of the batched one) runs: the two are compared through the oracle by every
-// batched-kernel test (tests/test_gpu_parity.py, scripts/gpu_batch_check.sh).
+// conditions' boolean algebra in scalar registers.  The batched kernel is bound by instruction issue (profiles/r04_grid.md, section 5): this form
+// needs a third of the branched one's scalar and branch instructions at the same number of vector instructions (config 3: 4.07 -> 2.54 x 10^11
+// instructions per launch, 575 -> 448 ms).  Case by case the lines below cite the branched form above, which stays the form every other kernel
+// (and the reference-stream instantiation of the batched one) runs: the two are compared through the oracle by every batched-kernel test
+// (tests/test_gpu_parity.py, scripts/gpu_batch_check.sh).
 // ---------------------------------------------------------------------------------------------------------------------------------
 typedef int lmask;
 __device__ __forceinline__ lmask lm(const bool c) { int m = c ? -1 : 0; asm("" : "+v"(m)); return m; } // v_cmp + v_cndmask: no scalar instruction

@@ -407,8 +407,8 @@ def run_grid(args, pkg, eng, torch, dist, rank, world, dev, cdev, barrier):
                      "bytes": "the kernel's own bytes: 64 B per event UE (its 32-byte record streamed in and out, whole 64-record chunks) + 8 B per contention window (join-list entry), rank 0",
                      "own_bytes_per_update": sum(owns) / max(1, updates_per_step * args.steps / world),
                      "dense_formulation_GBps_32B_per_update": ALGO_BYTES_PER_UPDATE * updates_per_step / world / (sum(kmss) / args.steps * 1e-3) / 1e9,
-                     "note": "the launch is bound by instruction issue on the scalar side of the event body, not by HBM (profiles/r04_grid.md: counter traffic 0.77 B per "
-                             "update = 0.95 x the kernel's own bytes, 1.6 TB/s); the 32 B per update of the reference's dense formulation is not a lower bound for a "
+                     "note": "the launch is bound by instruction issue (0.58-0.66 of the SIMDs' vector issue slots over the whole launch, profiles/r04_grid.md section 5), "
+                             "not by HBM (counter traffic 0.78 B per update = 0.95 x the kernel's own bytes, 1.9 TB/s); the 32 B per update of the reference's dense formulation is not a lower bound for a "
                              "kernel that only touches a UE at its events (dense_formulation_GBps is carried for the record: several times the chip's peak)"},
         # The N = 1 line of the driver's scaling run is the single-trial workload (configs[1]), a DIFFERENT workload: the one-GPU figure of this
         # grid regime travels in that same N = 1 line as extras.grid_one_gpu (measured in that run, --times 100), and every N > 1 line carries
