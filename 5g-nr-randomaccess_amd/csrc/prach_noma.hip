@@ -227,6 +227,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
 #ifdef PRACH_STAMPS // (make DIAG=1; PRACH_PRINT_STAMPS=1 prints them per SUBFRAME: x accessTime = per slot; workgroup 0, wavefront 0)
     unsigned long long fstamps[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fprev = __builtin_readcyclecounter();
 #endif
+    unsigned long long dead0 = 0ull, dead1 = 0ull; // this wavefront's groups (in the order it visits them) that pass B no longer has to look at
     for (int s = 0, t0 = 0; t0 < P.stop && status == PRACH_OK; s++, t0 += aT) {
         const int t = t0; // the slot's subframe (time % accessTime == 0)
         NSTAMP(0); // loop head
@@ -308,7 +309,8 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     bool ambiguous = false;
                     if (lane < count) {
                         uidx = L.sidx[sct * 64 + lane]; ug = L.sg[sct * 64 + lane]; ulg = L.slg[sct * 64 + lane];
-                        for (int j = 0; j < count; j++) {
+#pragma unroll 8
+                        for (int j = 0; j < count; j++) { // (unrolled: eight broadcast reads in flight instead of one LDS round trip per comparison)
                             const double gj = L.sg[sct * 64 + j];
                             rank += (gj < ug || (gj == ug && j < lane)) ? 1 : 0;
                         }
@@ -324,13 +326,20 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     if (devact && lane + 1 < count) { const double ga = L.sg[sct * 64 + lane], gb = L.sg[sct * 64 + lane + 1]; if (__dsub_rn(gb, ga) <= ACT_GAIN_ORDER_BAND * gb || P.n_devact == 2) ambiguous = true; }
                     NSTAMP(9); // resolve: ranked and sorted
                     unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
+                    const double clg10 = __dmul_rn(10.0, clg); // (NOMA.c:272: 10 * log(gain), the same product on either side of the difference)
                     int grants = 0, npd = 0;
                     bool grantme = false;
-                    for (int i = 0; i < count - 1; i++) { // NOMA.c:268-298
-                        if (!((valid >> i) & 1ull)) continue;
-                        const double lgi = __shfl(clg, i);
-                        const double diff = __dsub_rn(__dmul_rn(10.0, clg), __dmul_rn(10.0, lgi)); // 10*log(high) - 10*log(low)
-                        const bool cond = lane > 0 && lane != i && lane < count && ((valid >> lane) & 1ull) && diff > 15.0;
+                    const unsigned long long lows = count >= 2 ? ((1ull << (count - 1)) - 1ull) : 0ull; // i < count - 1
+                    unsigned long long above = ~0ull;                                                    // bits behind the last i looked at
+                    for (;;) { // NOMA.c:268-298, over the still unpaired i in ascending order
+                        const unsigned long long rest = valid & lows & above;
+                        if (!rest) break;
+                        const int i = __ffsll((long long)rest) - 1;
+                        above = ~((2ull << i) - 1ull);
+                        // (lane i's 10 ln g through two v_readlane — i is wave-uniform — instead of a ds_bpermute round trip per comparison: this loop is a latency chain)
+                        const double lgi10 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(clg10), i), __builtin_amdgcn_readlane(__double2loint(clg10), i));
+                        const double diff = __dsub_rn(clg10, lgi10); // 10*log(high) - 10*log(low)
+                        const bool cond = lane > 0 && lane != i && ((valid >> lane) & 1ull) && diff > 15.0;
                         if (devact && lane < count && fabs(__dsub_rn(diff, 15.0)) < 1e-9) ambiguous = true; // (|error| of 10 ln g1 - 10 ln g2 < 1e-12)
                         const unsigned long long mj = __ballot(cond);
                         if (!mj) continue;
@@ -375,15 +384,16 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             const bool has_next = t0 + aT < P.stop;
             int c_succ = 0, c_maxt = -1;
             for (int k = tid; k < nb; k += WG_THREADS) { L.tcnt[k] = 0; L.twho[k] = INT_MAX; } // (the resolver is done with them)
-            for (int j = w;; j += NW) {
+            for (int j = w, jl = 0;; j += NW, jl++) {
                 const int g = b + G * j;
                 if (g >= ngroups) break;
+                if (jl < 128 && ((jl < 64 ? dead0 >> jl : dead1 >> (jl - 64)) & 1ull)) continue; // nothing can happen to any UE of this group any more (below): not even loaded
                 const int i = g * 64 + lane;
                 int4 r = make_int4(0, 0, 0, 0);
                 if (i < activeCheck) r = load_rec(&P.rec[i]);
                 unsigned pk = (unsigned)r.w;
                 bool alive = i < activeCheck && !(pk & (N_RA_BIT | N_FAIL_BIT));
-                if (!__any(alive || (i >= activeCheck && i < acNext))) continue;
+                if (!__any(alive || (i >= activeCheck && i < acNext))) { if (__all(i < activeCheck || i >= nUE)) { if (jl < 64) dead0 |= 1ull << jl; else if (jl < 128) dead1 |= 1ull << (jl - 64); } continue; }
                 bool dirty = false, nd_loaded = false;
                 unsigned k = 0;
                 // -- msg2Results (NOMA.c:692-696 -> :449-498) --
@@ -431,9 +441,13 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     }
                 }
                 // -- resourceRequestAllocation, subframes t0 .. tend_slot-1 (NOMA.c:699 -> :499-546) --
-                for (int tt = t0; tt < tend_slot; tt++) {
-                    const bool m3 = alive && (pk & 3) == 2 && (pk & N_MSG2_BIT) && r.x == tt;
-                    if (!__any(m3)) continue;
+                // (every lane takes its OWN subframe tt = txTime of the slot in one step — UEs are independent — instead of a loop over the slot's subframes with wave-wide
+                //  draws in each: a UE has one such subframe per slot unless accessTime exceeds the 49 subframes a failed Msg3 waits, hence the loop around it)
+                for (;;) {
+                    const int tt = r.x;
+                    const bool m3 = alive && (pk & 3) == 2 && (pk & N_MSG2_BIT) && tt >= t0 && tt < tend_slot;
+                    if (!__any(m3)) break;
+                    {
                     const bool m3first = m3 && !(pk & N_M3W_BIT), m3to = m3 && (pk & N_M3W_BIT);
                     if (m3 && !nd_loaded) { k = P.nd[i]; nd_loaded = true; }
                     const int d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, NOMA_VARIANT);
@@ -464,11 +478,21 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         dirty = true;
                     }
                 }
+                }
                 if (nd_loaded) P.nd[i] = k;
                 r.w = (int)pk;
                 // -- the NEXT slot's pass A on the record as it stands now: one load and one store per UE and slot --
                 if (has_next) pass_a_lane(i, r, dirty, t0 + aT, activeCheck, acNext);
                 if (dirty) store_rec(&P.rec[i], r);
+                {
+                    // A UE acts only in a subframe its txTime names (msg2Results: txTime == slot + 1, NOMA.c:449-455; resourceRequestAllocation: txTime == subframe,
+                    // NOMA.c:499-502), and only acting changes txTime: one whose txTime lies before the next slot's (it was in backoff at its last slot, ~1 % of the UEs)
+                    // only ticks its timer from here on — and timers are stored as bases.  A group of which every UE has arrived and is finished, dropped or such a
+                    // sleeper is never loaded again (bit-exact: its records never change).
+                    const unsigned st = pk & 3u;
+                    const bool over = i >= nUE || (i < activeCheck && ((pk & (N_RA_BIT | N_FAIL_BIT)) != 0u || (st == 1u && r.x < t0 + aT + 1) || (st == 2u && r.x < t0 + aT)));
+                    if (has_next && __all(over)) { if (jl < 64) dead0 |= 1ull << jl; else if (jl < 128) dead1 |= 1ull << (jl - 64); }
+                }
             }
             c_succ = wave_sum(c_succ); c_maxt = wave_max(c_maxt);
             if (lane == 0 && c_succ) { atomicAdd(&L.scal[N_NSUCC], c_succ); atomicMax(&L.scal[N_MAXT], c_maxt); }
