@@ -194,16 +194,18 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
     // pass A for one UE of the slot whose subframe is tA: activation of the newly arrived (activeUE, NOMA.c:131-140: everything
     // else comes from the activation table) and the transmitter gather (NOMA.c:207: RA==0, txTime==time+1, msg2==0,
     // nowBackoff<=0, RaFailed==0) into this workgroup's (sector, preamble) bins
-    auto pass_a_lane = [&](const int i, int4 &r, bool &dirty, const int tA, const int prevA, const int acA) {
+    // (pre0v / nd0v / secv: the UE's activation-table entries, loaded by the caller TOGETHER with the record: they do not depend on it, and a busy group's pass is a
+    //  chain of global round trips otherwise — record, draw index, sector, one after the other)
+    auto pass_a_lane = [&](const int i, int4 &r, bool &dirty, const int tA, const int prevA, const int acA, const int pre0v, const unsigned nd0v, const int secv) {
         if (i >= prevA && i < acA) {
             r.x = tA + 1; r.y = tA; r.z = 0;
-            r.w = 1 | (pre0[i] << N_PRE_SHIFT);
-            P.ptc[i] = 1; P.ftt[i] = tA + 1; P.nd[i] = P.n_nd0[i];
+            r.w = 1 | (pre0v << N_PRE_SHIFT);
+            P.ptc[i] = 1; P.ftt[i] = tA + 1; P.nd[i] = nd0v;
             dirty = true;
         }
         const unsigned pk = (unsigned)r.w;
         if (i < acA && (pk & 3) == 1 && !(pk & (N_RA_BIT | N_FAIL_BIT | N_MSG2_BIT)) && r.x == tA + 1 && now_backoff(r.z, tA) <= 0) {
-            const int bin = (nonsector ? 0 : sector[i]) * nP + (int)((pk >> N_PRE_SHIFT) & 0xff);
+            const int bin = (nonsector ? 0 : secv) * nP + (int)((pk >> N_PRE_SHIFT) & 0xff);
             atomicAdd(&L.cnt[bin], 1);
             atomicMin(&L.who[bin], i);
         }
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
             const int i = g * 64 + lane;
             int4 r = make_int4(0, 0, 0, 0);
             bool dirty = false;
-            pass_a_lane(i, r, dirty, 0, 0, ac0); // (nothing is active before slot 0: no record to load)
+            const bool in0 = i < ac0;
+            pass_a_lane(i, r, dirty, 0, 0, ac0, in0 ? pre0[i] : 0, in0 ? P.n_nd0[i] : 0u, in0 && !nonsector ? sector[i] : 0); // (nothing is active before slot 0: no record to load)
             if (dirty) store_rec(&P.rec[i], r);
         }
     }
@@ -390,12 +393,15 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                 if (jl < 128 && ((jl < 64 ? dead0 >> jl : dead1 >> (jl - 64)) & 1ull)) continue; // nothing can happen to any UE of this group any more (below): not even loaded
                 const int i = g * 64 + lane;
                 int4 r = make_int4(0, 0, 0, 0);
-                if (i < activeCheck) r = load_rec(&P.rec[i]);
+                unsigned k = 0, nd0v = 0;
+                int pre0v = 0, secv = 0;
+                if (i < activeCheck) { r = load_rec(&P.rec[i]); k = P.nd[i]; } // (the draw index rides along: only this wavefront ever writes it)
+                if (i < acNext && !nonsector) secv = sector[i];
+                if (i >= activeCheck && i < acNext) { pre0v = pre0[i]; nd0v = P.n_nd0[i]; }
                 unsigned pk = (unsigned)r.w;
                 bool alive = i < activeCheck && !(pk & (N_RA_BIT | N_FAIL_BIT));
                 if (!__any(alive || (i >= activeCheck && i < acNext))) { if (__all(i < activeCheck || i >= nUE)) { if (jl < 64) dead0 |= 1ull << jl; else if (jl < 128) dead1 |= 1ull << (jl - 64); } continue; }
-                bool dirty = false, nd_loaded = false;
-                unsigned k = 0;
+                bool dirty = false, nd_loaded = false; // (nd_loaded: the draw index moved and has to be stored)
                 // -- msg2Results (NOMA.c:692-696 -> :449-498) --
                 const bool tx = alive && (pk & 3) == 1 && r.x == t + 1 && now_backoff(r.z, t) <= 0;
                 if (__any(tx)) {
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     const bool perm = txfail && rar_expires && retx + 1 >= P.maxMsg2; // msg1ReTx reaches maxMsg1ReTx: dropped for good
                     int d1 = 0, d2 = 0;
                     if (rar_expires && __any(txfail)) {
-                        if (txfail) { k = P.nd[i]; nd_loaded = true; }
+                        if (txfail) nd_loaded = true;
                         d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, NOMA_VARIANT);
                         if (__any(perm)) d2 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, NOMA_VARIANT);
                         if (txfail) k += perm ? 2u : 1u;
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                     if (!__any(m3)) break;
                     {
                     const bool m3first = m3 && !(pk & N_M3W_BIT), m3to = m3 && (pk & N_M3W_BIT);
-                    if (m3 && !nd_loaded) { k = P.nd[i]; nd_loaded = true; }
+                    if (m3) nd_loaded = true;
                     const int d1 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k, (unsigned)nUE, NOMA_VARIANT);
                     int d2 = 0;
                     if (__any(m3to)) d2 = philox_draw31(P.seed_lo, P.seed_hi, (unsigned)i, k + 1, (unsigned)nUE, NOMA_VARIANT);
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                 if (nd_loaded) P.nd[i] = k;
                 r.w = (int)pk;
                 // -- the NEXT slot's pass A on the record as it stands now: one load and one store per UE and slot --
-                if (has_next) pass_a_lane(i, r, dirty, t0 + aT, activeCheck, acNext);
+                if (has_next) pass_a_lane(i, r, dirty, t0 + aT, activeCheck, acNext, pre0v, nd0v, secv);
                 if (dirty) store_rec(&P.rec[i], r);
                 {
                     // A UE acts only in a subframe its txTime names (msg2Results: txTime == slot + 1, NOMA.c:449-455; resourceRequestAllocation: txTime == subframe,
