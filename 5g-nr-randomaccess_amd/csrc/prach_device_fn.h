@@ -2,36 +2,41 @@
 #pragma once
 #include "prach_device.h"
 
+// The per-UE state machine (prach_ue_body.h) and the arithmetic it rests on are host-callable as well: tests/tools/flat_equiv.hip runs the branched and the
+// branch-free form side by side on the CPU (pytest -m "not gpu"), no GPU involved.
+#define PRACH_HD __host__ __device__ __forceinline__
+
 namespace prach {
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int slot_align(int sub, int aT) { // Beta.c:268-277
+PRACH_HD int slot_align(int sub, int aT) { // Beta.c:268-277
     const int m = sub % aT;
     return m == 0 ? sub + 1 : (m == 1 ? sub : sub + (aT - m + 1));
 }
 // x % d for a wave-uniform divisor d and 0 <= x < 2^32: one mul-hi + one correction instead of the
 // ~40-instruction software division (M = floor(2^32 / d); the quotient estimate is at most 1 short)
 struct FastMod { unsigned d, M; };
-__device__ __forceinline__ FastMod make_fastmod(int d) {
+PRACH_HD unsigned mulhi32(const unsigned a, const unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); } // (v_mul_hi_u32; __umulhi is device-only)
+PRACH_HD FastMod make_fastmod(int d) {
     FastMod f;
     f.d = (unsigned)d;
     f.M = d > 1 ? (unsigned)(0x100000000ull / (unsigned long long)d) : (d == 1 ? 0xFFFFFFFFu : 0u); // (d == 1: q = x - 1 for x > 0, so r = 1 and the correction gives 0 without a special case)
     return f;
 }
-__device__ __forceinline__ int fastmod(int x, const FastMod f) {
+PRACH_HD int fastmod(int x, const FastMod f) {
     if (f.d == 1u) return 0;
-    const unsigned q = __umulhi((unsigned)x, f.M);
+    const unsigned q = mulhi32((unsigned)x, f.M);
     const unsigned r = (unsigned)x - q * f.d;
     return (int)(r >= f.d ? r - f.d : r);
 }
-__device__ __forceinline__ int slot_align_fm(int sub, const FastMod aT) { // Beta.c:268-277
+PRACH_HD int slot_align_fm(int sub, const FastMod aT) { // Beta.c:268-277
     const int m = fastmod(sub, aT);
     return m == 0 ? sub + 1 : (m == 1 ? sub : sub + ((int)aT.d - m + 1));
 }
-__device__ __forceinline__ int now_backoff(int bo, int t) { return bo > 0 ? max(bo - t, 0) : bo; }
-__device__ __forceinline__ int enc_backoff(int X, int t) { return X > 0 ? t + X : X; }
+PRACH_HD int now_backoff(int bo, int t) { return bo > 0 ? max(bo - t, 0) : bo; }
+PRACH_HD int enc_backoff(int X, int t) { return X > 0 ? t + X : X; }
 
 // Philox4x32-10 (the draw = word 0 of the block >> 1).  Written for gfx950's instruction set: one v_mad_u64_u32 per 32 x 32 -> 64 product (the compiler
 // emits a v_mul_hi_u32 + v_mul_lo_u32 pair for __umulhi and *), one v_bitop3_b32 per three-way xor — 6 vector instructions per round instead of 10.  The
@@ -231,14 +236,14 @@ template <class T> __device__ __forceinline__ void gmax(PRACH_G T *p, const T v)
 struct UeState {
     int tx, tb, bo, act, conn, pre, rar, mrc, pend;
 };
-__device__ __forceinline__ UeState unpack(const int4 r) {
+PRACH_HD UeState unpack(const int4 r) {
     UeState u;
     u.tx = r.x; u.tb = r.y; u.bo = r.z;
     u.act = (r.w >> PK_ACT_SHIFT) & 3; u.conn = (r.w >> PK_CONN_SHIFT) & 3; u.pre = (r.w >> PK_PRE_SHIFT) & 0xff;
     u.rar = (r.w >> PK_RAR_SHIFT) & 0xff; u.mrc = (r.w >> PK_MRC_SHIFT) & 0xff; u.pend = (r.w >> PK_PEND_SHIFT) & 7;
     return u;
 }
-__device__ __forceinline__ int4 pack(const UeState &u) {
+PRACH_HD int4 pack(const UeState &u) {
     return make_int4(u.tx, u.tb, u.bo,
                      (u.act << PK_ACT_SHIFT) | (u.conn << PK_CONN_SHIFT) | (u.pre << PK_PRE_SHIFT) | (u.rar << PK_RAR_SHIFT) |
                          (u.mrc << PK_MRC_SHIFT) | (u.pend << PK_PEND_SHIFT));

@@ -45,24 +45,24 @@ struct ColdGlobal {
 // ... in registers, as part of a record the lane has loaded and will store back
 struct ColdRegs {
     int ptc, ftt, stt, fcnt;
-    __device__ __forceinline__ void ptc_set1(const int) { ptc = 1; }
-    __device__ __forceinline__ void ptc_inc(const int) { ptc++; }
-    __device__ __forceinline__ void ftt_set(const int, const int v) { ftt = v; }
-    __device__ __forceinline__ void stt_set(const int, const int v) { stt = v; }
-    __device__ __forceinline__ void fcnt_zero(const int) { fcnt = 0; }
-    __device__ __forceinline__ void fcnt_inc(const int) { fcnt++; }
+    PRACH_HD void ptc_set1(const int) { ptc = 1; }
+    PRACH_HD void ptc_inc(const int) { ptc++; }
+    PRACH_HD void ftt_set(const int, const int v) { ftt = v; }
+    PRACH_HD void stt_set(const int, const int v) { stt = v; }
+    PRACH_HD void fcnt_zero(const int) { fcnt = 0; }
+    PRACH_HD void fcnt_inc(const int) { fcnt++; }
 };
 // first / last caller per bucket of the previous subframe, as plain tables (LDS)
 struct CallTables {
     const int *fc, *lc;
-    __device__ __forceinline__ int fcall(const int q) const { return fc[q]; }
-    __device__ __forceinline__ int lcall(const int p) const { return lc[p]; }
+    PRACH_HD int fcall(const int q) const { return fc[q]; }
+    PRACH_HD int lcall(const int p) const { return lc[p]; }
 };
 
 // ---- deferred outcome of subframe tp = t - 1 (preambleCollision's side effects, Beta.c:332-366) -------------------------------
 // granted: the resolver gave this (singleton-calling) UE an UL grant.  Returns true if the state changed.
 template <class TAB>
-__device__ __forceinline__ bool ue_apply(UeState &u, const bool granted, const int i, const int tp, const FastMod fmA, const TAB &tab) {
+PRACH_HD bool ue_apply(UeState &u, const bool granted, const int i, const int tp, const FastMod fmA, const TAB &tab) {
     if (u.pend == PEND_NONE) return false;
     if (granted) { // Beta.c:338-343
         u.act = ACT_M3; u.tx = tp + 11; u.conn = 0;
@@ -86,7 +86,7 @@ __device__ __forceinline__ bool ue_apply(UeState &u, const bool granted, const i
 
 // ---- activation (Beta.c:136-146; the two draws of activateUEs, WithNOMA:393-394, are the caller's business) -------------------
 template <class COLD>
-__device__ __forceinline__ void ue_activate(UeState &u, const int i, const int t, COLD &cold) {
+PRACH_HD void ue_activate(UeState &u, const int i, const int t, COLD &cold) {
     u.act = ACT_M1; u.tx = t + 1; u.tb = t;
     cold.ftt_set(i, t + 1);
 }
@@ -96,7 +96,7 @@ struct UePlan {
     bool isM1, firstsel, backoff, contend, reset, retx, m3first, m3to, busy;
     int need; // rand() calls of this UE in this subframe: 0, 1 or 2
 };
-__device__ __forceinline__ UePlan ue_plan(const UeState &u, const int t, const int maxRar, const int maxMsg2) {
+PRACH_HD UePlan ue_plan(const UeState &u, const int t, const int maxRar, const int maxMsg2) {
     UePlan p;
     p.isM1 = u.act == ACT_M1;
     const int nb = now_backoff(u.bo, t);
@@ -124,7 +124,7 @@ struct UeOut {
     bool dirty;           // the state changed
 };
 template <class COLD>
-__device__ __forceinline__ UeOut ue_select(UeState &u, const UePlan &pl, const int d1, const int d2, const int i, const int t, const int tmod, const UeK &K,
+PRACH_HD UeOut ue_select(UeState &u, const UePlan &pl, const int d1, const int d2, const int i, const int t, const int tmod, const UeK &K,
                                            COLD &cold, int &c_succ, int &c_contf) { // tmod = t mod accessTime
     UeOut o;
     o.evtype = UEV_NONE; o.evp = 0; o.evq = 0;
@@ -208,7 +208,7 @@ __device__ __forceinline__ UeOut ue_select(UeState &u, const UePlan &pl, const i
 constexpr unsigned PW_IDLE = 0x0000FFFFu;  // not arrived yet
 constexpr unsigned PW_DONE = 0x4000FFFFu;  // finished for good
 constexpr int PW_MAX_RAR = 64, PW_MAX_PREAMBLES = 64, PW_MAX_SUBFRAMES = 65000;
-__device__ __forceinline__ unsigned pw_make(const int tj, const int dur, const int pre) {
+PRACH_HD unsigned pw_make(const int tj, const int dur, const int pre) {
     return ((unsigned)tj & 0xFFFFu) | ((unsigned)dur << 16) | ((unsigned)pre << 24);
 }
 
@@ -216,7 +216,7 @@ __device__ __forceinline__ unsigned pw_make(const int tj, const int dur, const i
 // subframe s (ue_apply; a caller or matched UE was recorded with txTime = s + 1 already), then the subframes it was matched in since
 // according to the word it was scheduled with (sw) — bumped every time, one RAR-window subframe each.
 template <class TAB>
-__device__ __forceinline__ void pw_catch_up(UeState &u, const unsigned sw, const bool granted, const int i, const int t, const FastMod fmA, const TAB &tab) {
+PRACH_HD void pw_catch_up(UeState &u, const unsigned sw, const bool granted, const int i, const int t, const FastMod fmA, const TAB &tab) {
     const int tp = t - 1;
     if (u.pend == PEND_CALLER || u.pend == PEND_STAY) {
         if (granted) { u.act = ACT_M3; u.tx = tp + 11; u.conn = 0; } // (a grant is applied the very next subframe: s == tp)
@@ -231,7 +231,7 @@ __device__ __forceinline__ void pw_catch_up(UeState &u, const unsigned sw, const
 }
 
 // the schedule word of a UE after the event body of subframe t
-__device__ __forceinline__ unsigned pw_schedule(UeState &u, const int t, const int maxRar) {
+PRACH_HD unsigned pw_schedule(UeState &u, const int t, const int maxRar) {
     if (u.act == ACT_DONE) return PW_DONE;
     if (u.act == ACT_M3) return u.tx > t ? pw_make(u.tx, 0, 0) : PW_IDLE; // Msg3 / Msg4 at txTime (a txTime in the past never comes: Beta.c:167)
     if (u.pend == PEND_RESET || u.pend == PEND_PASSIVE || u.pend == PEND_RJOIN) return pw_make(t + 1, 0, 0); // outcome needs the caller tables of t
@@ -257,14 +257,21 @@ __device__ __forceinline__ unsigned pw_schedule(UeState &u, const int t, const i
 // (tests/test_gpu_parity.py, scripts/gpu_batch_check.sh).
 // ---------------------------------------------------------------------------------------------------------------------------------
 typedef int lmask;
-__device__ __forceinline__ lmask lm(const bool c) { int m = c ? -1 : 0; asm("" : "+v"(m)); return m; } // v_cmp + v_cndmask: no scalar instruction
-__device__ __forceinline__ int lsel(const lmask m, const int a, const int b) { return (a & m) | (b & ~m); } // v_bfi_b32
-__device__ __forceinline__ int fastmod_flat(const int x, const FastMod f) { // = fastmod
-    const unsigned q = __umulhi((unsigned)x, f.M);
-    const unsigned r = (unsigned)x - q * f.d;
-    return (int)min(r, r - f.d); // (r - d wraps above r when r < d; d == 1: make_fastmod's M makes r = 1 for x > 0)
+PRACH_HD lmask lm(const bool c) { // v_cmp + v_cndmask: no scalar instruction
+    int m = c ? -1 : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(m)); // (the value is opaque from here on: the compiler cannot turn the mask algebra back into branches / scalar-register booleans)
+#endif
+    return m;
 }
-__device__ __forceinline__ int slot_align_flat(const int sub, const FastMod aT) { // = slot_align_fm: m == 0: sub + 1, m == 1: sub, else sub + (aT - m + 1)
+PRACH_HD int lsel(const lmask m, const int a, const int b) { return (a & m) | (b & ~m); } // v_bfi_b32
+PRACH_HD int fastmod_flat(const int x, const FastMod f) { // = fastmod
+    const unsigned q = mulhi32((unsigned)x, f.M);
+    const unsigned r = (unsigned)x - q * f.d;
+    const unsigned r2 = r - f.d; // (wraps above r when r < d; d == 1: make_fastmod's M makes r = 1 for x > 0)
+    return (int)(r2 < r ? r2 : r); // = v_min_u32 (spelled out: on the host `min` of two unsigned picks the int overload)
+}
+PRACH_HD int slot_align_flat(const int sub, const FastMod aT) { // = slot_align_fm: m == 0: sub + 1, m == 1: sub, else sub + (aT - m + 1)
     const int m = fastmod_flat(sub, aT);
     return sub + ((int)aT.d + 1 - m) - ((int)aT.d & lm(m < 2));
 }
@@ -272,7 +279,7 @@ __device__ __forceinline__ int slot_align_flat(const int sub, const FastMod aT) 
 // pw_catch_up: the record as the event body left it (scheduled with a window of sdur subframes ending at t) brought to the start of subframe tcu
 // (t, or the subframe after the UL grant noted for it)
 template <class TAB>
-__device__ __forceinline__ void flat_catch_up(UeState &u, const int sdur, const lmask granted, const int i, const int t, const int tcu, const FastMod fmA, const TAB &tab) {
+PRACH_HD void flat_catch_up(UeState &u, const int sdur, const lmask granted, const int i, const int t, const int tcu, const FastMod fmA, const TAB &tab) {
     const int tp = tcu - 1;
     const lmask mreset = lm(u.pend == PEND_RESET), mpass = lm(u.pend == PEND_PASSIVE), mrj = lm(u.pend == PEND_RJOIN);
     const int fc = tab.fcall(lsel(mreset, u.bo, u.pre - 1) & 63), lc = tab.lcall((u.pre - 1) & 63); // (every lane reads: the tables are LDS)
@@ -292,7 +299,7 @@ __device__ __forceinline__ void flat_catch_up(UeState &u, const int sdur, const 
 }
 
 struct FlatPlan { lmask isM1, pre0, firstsel, backoff, reset, retx, stay, m3first, m3to; int need; };
-__device__ __forceinline__ FlatPlan flat_plan(const UeState &u, const int t, const int maxRar, const int maxMsg2) { // = ue_plan
+PRACH_HD FlatPlan flat_plan(const UeState &u, const int t, const int maxRar, const int maxMsg2) { // = ue_plan
     FlatPlan p;
     p.isM1 = lm(u.act == ACT_M1); p.pre0 = lm(u.pre == 0);
     const lmask inbo = lm(u.bo > t); // now_backoff(bo, t) > 0 (t >= 0)
@@ -313,7 +320,7 @@ __device__ __forceinline__ FlatPlan flat_plan(const UeState &u, const int t, con
 // what finish() of prach_batch.hip needs of a UE's subframe
 struct FlatOut { int evtype, evp, evq, oldp; lmask member_pre, eclass; unsigned word; };
 // = ue_select (ColdRegs only: the cold fields ride in the record)
-__device__ __forceinline__ FlatOut flat_select(UeState &u, ColdRegs &cold, const FlatPlan &p, const int d1, const int d2, const int t, const lmask rc_slot /* aT > 1 && t mod aT == 1 */,
+PRACH_HD FlatOut flat_select(UeState &u, ColdRegs &cold, const FlatPlan &p, const int d1, const int d2, const int t, const lmask rc_slot /* aT > 1 && t mod aT == 1 */,
                                                const UeK &K, const lmask withnoma, int &c_succ, int &c_contf) {
     FlatOut o;
     const int oldp = u.pre - 1;
@@ -365,7 +372,7 @@ __device__ __forceinline__ FlatOut flat_select(UeState &u, ColdRegs &cold, const
 }
 
 // = pw_schedule
-__device__ __forceinline__ unsigned flat_schedule(UeState &u, const int t, const int maxRar) {
+PRACH_HD unsigned flat_schedule(UeState &u, const int t, const int maxRar) {
     const lmask done = lm(u.act == ACT_DONE), m3 = lm(u.act == ACT_M3), m1 = ~(done | m3);
     const lmask px = lm((unsigned)(u.pend - PEND_RESET) < 3u), pcs = lm((unsigned)(u.pend - PEND_STAY) < 2u);
     u.tx = lsel(m1 & pcs, t + 1, u.tx);
@@ -378,13 +385,13 @@ __device__ __forceinline__ unsigned flat_schedule(UeState &u, const int t, const
     return ((unsigned)tj & 0xFFFFu) | ((unsigned)dur << 16) | ((unsigned)pre << 24) | (0x40000000u & (unsigned)done);
 }
 // = ue_event_info
-__device__ __forceinline__ int flat_event_info(const FlatOut &o) {
+PRACH_HD int flat_event_info(const FlatOut &o) {
     const int ispre = 1 & ((lm(o.evtype == UEV_CALLER) & o.member_pre & lm(o.oldp == o.evp)) | (lm(o.evtype == UEV_RESETCAND) & lm(o.evp == o.evq)));
     return o.evtype | (ispre << 3) | (o.evp << 4) | (o.evq << 12);
 }
 
 // resolver-side info word of a special event (20 bits): type[2:0] ispre[3] bucket p[11:4] old bucket q[19:12]
-__device__ __forceinline__ int ue_event_info(const UeOut &o) {
+PRACH_HD int ue_event_info(const UeOut &o) {
     const int ispre = (o.evtype == UEV_CALLER) ? (o.member_pre && o.oldp == o.evp) : (o.evtype == UEV_RESETCAND ? (o.evp == o.evq) : 0);
     return o.evtype | (ispre << 3) | (o.evp << 4) | (o.evq << 12);
 }

@@ -197,3 +197,21 @@ def test_noma_cell_radius_must_exceed_the_redraw_threshold(pkg):
     assert pkg.lib().prach_cfg_validate(ok) == pkg.OK and pkg.lib().prach_cfg_validate(bad) == -1  # PRACH_ERR_ARG
     beta = pkg.make_cfg(100, cellRadius=1.0)  # (the other programs parse the flag and never read it: WithNOMA:80-82)
     assert pkg.lib().prach_cfg_validate(beta) == pkg.OK
+
+
+def test_branch_free_event_body_equals_the_branched_form(tmp_path):
+    """prach_batch.hip's event body runs prach_ue_body.h's state machine in a branch-free form (flat_catch_up / flat_plan / flat_select / flat_schedule);
+    every other kernel, and the oracle-checked history of this one, runs the branched form (pw_catch_up / ue_plan / ue_select / pw_schedule).  Both are
+    host-callable: tests/tools/flat_equiv.hip runs them side by side on the CPU on random UE states, parameters, caller tables and draws (random also where the
+    UE needs none: an unneeded draw may reach no output) and stops at the first difference.  No GPU involved; hipcc only compiles the host program."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "flat_equiv")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "tools", "flat_equiv.hip"), "-o", exe])
+    for seed in (11, 12):
+        p = subprocess.run([exe, "2000000", str(seed)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and " 0 differences" in p.stdout, p.stdout[-2000:]
