@@ -1008,3 +1008,16 @@ print("RESULT", res.status, tm.fallback_trials, tm.spin_timeouts, int((a != b).a
     status, fallback, timeouts, differs, same_succ, wall = int(line[1]), int(line[2]), int(line[3]), int(line[4]), line[5], float(line[6])
     assert (status, fallback, timeouts, differs, same_succ) == (0, 1, 0, 0, "True"), out.stdout + out.stderr[-1500:]
     assert wall < 5.0, f"the overflowing cluster took {wall} s: its workgroups waited for each other"
+
+
+@pytest.mark.gpu
+def test_branch_free_event_body_equals_the_branched_form_on_the_device(tmp_path):
+    """tests/test_host_logic.py's comparison with both forms compiled FOR THE DEVICE: every thread of a kernel runs prach_ue_body.h's branched and branch-free
+    state machine on the same random case (states, parameters, caller tables, draws — random also where none is needed) and compares field by field."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "gpu_flat_equiv")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "tools", "gpu_flat_equiv.hip"), "-o", exe])
+    p = subprocess.run([exe, "4000000", "21"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and " 0 differences" in p.stdout, p.stdout[-2000:]

@@ -19,7 +19,7 @@ struct Case {
     UeK K; int fc[64], lc[64];
 };
 
-static void gen(Case &c) {
+static void gen(Case &c) { // (host only: the generator)
     const int nP = rnd() % 4 ? rint_(1, 64) : (int[]){1, 2, 54, 64}[rnd() % 4];
     const int backoff = rnd() % 4 ? rint_(1, 80) : rint_(1, 2), aT = rnd() % 4 == 0 ? 1 : (rnd() % 3 ? rint_(1, 20) : 5); // (short backoffs / accessTime 1: re-joins in the same subframe)
     c.K.maxRar = rint_(1, 11); c.K.maxMsg2 = (int[]){0, 1, 2, 3, 9, 10, 20}[rnd() % 7]; c.K.aT = aT; c.K.withnoma = rnd() & 1;
@@ -61,7 +61,7 @@ static void gen(Case &c) {
 
 struct Out { UeState u; ColdRegs cold; int need, evtype, evp, evq, member, eclass, info, cs, cc; unsigned word; };
 
-static Out run_branched(const Case &c) {
+static __host__ __device__ Out run_branched(const Case &c) {
     Out o; o.u = c.u; o.cold = c.cold; o.cs = 0; o.cc = 0;
     const CallTables tab{c.fc, c.lc};
     if (!(c.u.act == ACT_M1 && c.u.pre == 0 && c.u.tx == c.t + 1)) // (an arrival is not caught up: prach_batch.hip)
@@ -73,7 +73,7 @@ static Out run_branched(const Case &c) {
     o.word = c.u.act == ACT_IDLE ? PW_IDLE : pw_schedule(o.u, c.t, c.K.maxRar);
     return o;
 }
-static Out run_flat(const Case &c) {
+static __host__ __device__ Out run_flat(const Case &c) {
     Out o; o.u = c.u; o.cold = c.cold; o.cs = 0; o.cc = 0;
     const CallTables tab{c.fc, c.lc};
     if (!(c.u.act == ACT_M1 && c.u.pre == 0 && c.u.tx == c.t + 1))
@@ -86,7 +86,7 @@ static Out run_flat(const Case &c) {
     o.word = c.u.act == ACT_IDLE ? PW_IDLE : flat_schedule(o.u, c.t, c.K.maxRar);
     return o;
 }
-static bool same(const Out &a, const Out &b) {
+static __host__ __device__ bool same(const Out &a, const Out &b) {
     const bool idle = a.u.act == ACT_IDLE; // (a lane without a record: only that nothing is reported for it)
     return a.need == b.need && a.evtype == b.evtype && a.evp == b.evp && a.evq == b.evq && a.member == b.member && a.eclass == b.eclass && a.cs == b.cs && a.cc == b.cc &&
            (a.evtype == 0 || a.info == b.info) && a.word == b.word &&
@@ -98,6 +98,7 @@ static void show(const char *name, const Out &o) {
            o.need, o.evtype, o.evp, o.evq, o.member, o.eclass, o.info, o.cs, o.cc, o.word, o.u.tx, o.u.tb, o.u.bo, o.u.act, o.u.conn, o.u.pre, o.u.rar, o.u.mrc, o.u.pend, o.cold.ptc, o.cold.ftt, o.cold.stt, o.cold.fcnt);
 }
 
+#ifndef FLAT_EQUIV_NO_MAIN
 int main(int argc, char **argv) {
     const long n = argc > 1 ? atol(argv[1]) : 2000000;
     rng_s = 0x9E3779B97F4A7C15ull ^ (uint64_t)(argc > 2 ? atol(argv[2]) : 1);
@@ -117,3 +118,4 @@ int main(int argc, char **argv) {
     printf("flat_equiv: %ld cases, 0 differences (draws needed: none %ld, one %ld, two %ld; special events %ld)\n", n, needs[0], needs[1], needs[2], events);
     return 0;
 }
+#endif
