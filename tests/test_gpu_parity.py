@@ -1015,7 +1015,7 @@ def test_branch_free_event_body_equals_the_branched_form_on_the_device(tmp_path)
     """tests/test_host_logic.py's comparison with both forms compiled FOR THE DEVICE: every thread of a kernel runs prach_ue_body.h's branched and branch-free
     state machine on the same random case (states, parameters, caller tables, draws — random also where none is needed) and compares field by field."""
     import shutil
-    import subprocess
+    from conftest import ROOT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     exe = str(tmp_path / "gpu_flat_equiv")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "tools", "gpu_flat_equiv.hip"), "-o", exe])
