@@ -69,8 +69,8 @@ int prach_max_time(const prach_cfg *c) { return c->uniform ? 60000 : 10000; } /*
    on, linear in nUE); linear between the sweep's points, proportional beyond them, scaled by the subframes a shortened trial runs.  Uniform arrivals
    (60 000 subframes, a handful of live UEs each) and NOMA.c are costed by size alone: their sweeps deal evenly whatever the constant. */
 double prach_trial_cost(const prach_cfg *c) {
-    static const double beta_us[10] = {54.99, 89.81, 106.65, 121.23, 140.4, 190.78, 274.89, 369.38, 476.71, 589.0};
-    static const double over_us[10] = {59.74, 173.61, 280.2, 385.12, 493.9, 604.92, 717.54, 827.28, 935.91, 1044.71};
+    static const double beta_us[10] = {55.67, 81.6, 93.88, 105.34, 119.79, 156.88, 221.75, 293.07, 373.64, 455.66};
+    static const double over_us[10] = {57.24, 142.01, 219.44, 298.18, 376.92, 457.74, 538.67, 617.48, 693.07, 769.03};
     const double n = (double)c->nUE;
     const int maxt = prach_max_time(c);
     const double frac = (c->max_steps > 0 && c->max_steps < maxt) ? (double)c->max_steps / (double)maxt : 1.0;
