@@ -516,12 +516,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                         const lmask vm = arrival ? lm(ia < activeCheck) : lm(lane < (dcu >> 24));
                         R.a.w &= vm; // (a lane without a record: inactive, nothing pending — it takes no branch of the state machine and aims at the dummies)
                         unsigned nd = arrival ? (withnoma ? 2u : 0u) : ((unsigned)R.b.x & 0xFFFFFFu);
-                        int i = arrival ? ia : (R.b.w & 0xFFFFF);
-                        // The draws come FIRST, while only the raw record is held in registers (Philox's twenty temporaries on top of the unpacked state and the
-                        // plan's masks do not fit the wavefront's 128 registers: spilled ones are scratch loads that the in-order memory counter makes wait for the
-                        // next batch's records).  Whether any lane needs one or two is read off the packed word — never too few: a UE draws at its first selection
-                        // (arrival), when its RAR window expires (once; twice if the retransmissions are used up: Beta.c:250,282) and at Msg3 / its timeout
-                        // (Beta.c:372,384); an UL grant or a backoff found by the catch-up only takes draws away.
+                        const int i = arrival ? ia : (R.b.w & 0xFFFFF);
                         UeState u = unpack(R.a);
                         ColdRegs cold = cold_unpack(R.b);
                         if (arrival) { // ue_activate (Beta.c:136-146; activateUEs WithNOMA:383-394 also draws twice)
@@ -538,7 +533,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
                         }
                         const FlatPlan pl = flat_plan(u, t, K.maxRar, K.maxMsg2);
                         int d1 = 0, d2 = 0;
-                        if (__any(pl.need != 0)) {
+                        if (__any(pl.need != 0)) { // (draws only where a lane needs one, and behind the plan: the shape every digest and fuzzer covers — LABNOTES, round 4)
                             // (the key and the trial's two constant counter words enter Philox through an opaque copy made HERE: left to the compiler, the twenty round
                             //  keys and the first round's products are hoisted out of the step loop and held in 24 vector registers the whole kernel long — registers the
                             //  body does not have: it spilled to scratch, and a scratch load makes the in-order memory counter wait for the next batch's records)
