@@ -90,7 +90,7 @@ constexpr int EVB_CALLER = UEV_CALLER, EVB_RESETCAND = UEV_RESETCAND, EVB_RJOIN 
 
 // (the event / candidate counts and the free-chunk pool exist twice, by subframe parity: a wavefront that is already in the next subframe's body uses the other one)
 enum { B_NSUCC = 0, B_COLL, B_TXOP, B_CONTF, B_NS, B_NRC, B_NRJ, B_OVF /* the chunk pool, a chunk table or a join list is full: the trial leaves */, B_NEV = 8 /* [2] */, B_NCAND = 10 /* [2] */,
-       B_POOLH = 12 /* [2] free chunk ids in the shared pool's two halves */, B_PTC = 14, B_FC, B_SUMT = 16, B_ND = 18, B_JOINS = 20, B_EVENTS = 21, B_NCROSS = 22, B_BUMP = 23 /* chunks never used yet */,
+       B_POOLH = 12 /* [2] free chunk ids in the shared pool's two halves */, B_PTC = 14, B_FC, B_SUMT = 16, B_ND = 18, B_JOINS = 20, B_EVENTS = 21, B_NCROSS = 22, B_BUMP = 23 /* chunks never used yet */, B_TICK = 30 /* [2] event batches handed out beyond the wavefronts' own first three (second: the reference stream's select pass) */,
        B_SGC = 24 /* [24, 30): sectorGrants[6], WithNOMA:260 (PRACH_FLAG_SECTOR_GRANTS) */, B_NROV = 32 /* [16] grants beyond the first of their bucket, per subframe of the ring */ };
 
 // ---- LDS layout: byte offsets, all compile-time ------------------------------------------------------------------------------------
@@ -500,17 +500,29 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             // (GLIBC): the full body (branched form) with the draws at their stream positions (sbase: position of the subframe's first call of the UE loop).
             auto body_pass = [&](auto MODE_, const unsigned long long sbase) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(MODE_)::value;
-                int d_c = desc_of(w), d_n = desc_of(w + NWB);
-                BRec R_c = recs_of(d_c, w);
+                // A wavefront's first three batches are its own (w, w + NWB, w + 2 NWB: the pipeline's depth); every further one is drawn from a counter as the
+                // wavefront gets there, three batches ahead — batches differ (rare paths, partial chunks, the joins a wavefront did before), and the barrier behind
+                // the body waited a batch's length for the slowest wavefront when they were dealt round-robin.  (Drawing the first three from the counter as well
+                // was measured 9 % SLOWER on the grid: an exposed LDS round trip at the head of every subframe's body.)
+                int b_c = w, b_n = w + NWB, b_n2 = w + 2 * NWB;
+                int d_c = desc_of(b_c), d_n = desc_of(b_n);
+                BRec R_c = recs_of(d_c, b_c);
                 asm volatile("" :: "v"(R_c.a.x), "v"(R_c.a.y), "v"(R_c.a.z), "v"(R_c.a.w), "v"(R_c.b.x), "v"(R_c.b.y), "v"(R_c.b.z), "v"(R_c.b.w), "v"(d_n)); // (the first batch is waited for HERE, not at every batch's top)
-                for (int b = w; b < nb; b += NWB) {
-                    if (b + NWB < nb) { pR_n = recs_of(d_n, b + NWB); pd_n2 = desc_of(b + 2 * NWB); } // in flight while this batch is worked on
+                while (b_c < nb) {
+                    const int b = b_c;
+                    int tkv = 0; // (lane 0's add returns the ticket; it is read at the END of the batch: the LDS round trip is behind the batch's work)
+                    if (b_n2 < nb) tkv = atomicAdd(&lds[lane == 0 ? bl::SCAL / 4 + B_TICK + (MODE == 2 ? 1 : 0) : bl::DUMMY / 4 + lane], 1);
+                    if (b_n < nb) { pR_n = recs_of(d_n, b_n); pd_n2 = desc_of(b_n2); } // in flight while this batch is worked on
                     const bool arrival = b >= nch;
                     const int dcu = __builtin_amdgcn_readfirstlane(d_c);
                     BRec R = R_c;
                     if (!arrival && MODE != 1) chunk_free(dcu & 0xFFFFFF); // its records are in registers: the chunk can be filled again (by this wavefront, below)
                     // (the next batch moves into place at the END of this one, behind pipe_sync: a register move of a value still in flight would wait for it here)
-                    auto rotate = [&]() __attribute__((always_inline)) { d_c = d_n; d_n = pd_n2; R_c = pR_n; };
+                    auto rotate = [&]() __attribute__((always_inline)) {
+                        d_c = d_n; d_n = pd_n2; R_c = pR_n;
+                        const int b_n3 = b_n2 < nb ? 3 * NWB + __builtin_amdgcn_readfirstlane(tkv) : nb;
+                        b_c = b_n; b_n = b_n2; b_n2 = b_n3;
+                    };
                     const int ia = prevAC + (b - nch) * 64 + lane; // (arrival batches: Beta.c:136-146 in index order)
                     if constexpr (MODE == 0) {
                         const lmask vm = arrival ? lm(ia < activeCheck) : lm(lane < (dcu >> 24));
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
             }
             if (tid == 0) {
                 scal[B_EVENTS] += nch * 64 + narr; scal[B_JOINS] += nj; // (reported, never read by the simulation: records read, whole chunks)
-                scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0; scal[B_NROV + (t & 15)] = 0;
+                scal[B_NS] = 0; scal[B_NRC] = 0; scal[B_NRJ] = 0; scal[B_NROV + (t & 15)] = 0; scal[B_TICK] = 0; scal[B_TICK + 1] = 0;
                 nchk[slot] = 0; jcnt[slot] = 0; // (this slot is the subframe t + calmask + 1 from here on: nothing is scheduled that far ahead)
                 if (scal[B_POOLH + (parity ^ 1)] < 0) scal[B_POOLH + (parity ^ 1)] = 0; // (the half that was drawn from in this subframe takes the next subframe's free chunks)
             }
