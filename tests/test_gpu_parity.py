@@ -222,6 +222,45 @@ def test_config3_full_size_streaming_regime(pkg, ob, engine):
     assert [r.as_dict() for r in res2] == [r.as_dict() for r in res]
 
 
+def test_grid_full_size_streaming_regime(pkg, ob, engine):
+    """BASELINE configs[4]'s regime AS THE BENCH LAUNCHES IT ON ONE GPU (`grid_one_gpu`): --times 100 x the ten-point sweep = 1000 Beta.c-as-committed Philox trials
+    in ONE call (512-thread workgroups, two trials per CU, the branch-free event body).  Every counter of the ten trials of seed 0 and of the 100 000-UE trials of seeds
+    1..4 against the oracle, every logged field of every UE of the seed-0 100 000-UE trial; all 1000 through size-independent properties; both workgroup shapes agree."""
+    points = list(range(10000, 100001, 10000))
+    cfgs = [pkg.make_cfg(n, variant=pkg.VARIANT_BETA_C, rng_mode=pkg.RNG_PHILOX, seed=s) for s in range(100) for n in points]
+    want = [k for k, c in enumerate(cfgs) if c.nUE == 100000 and int(c.seed) == 0]
+    res, logs = engine.run_trials(cfgs, want_logs=want)
+    tm = engine.timing()
+    assert tm.launches == 1 and tm.workgroups == 1000 and tm.fallback_trials == 0 and tm.rec_mode == 4
+    import concurrent.futures as cf
+
+    def oracle(k):
+        c = cfgs[k]
+        return k, ob.run_trial(ob.make_cfg(c.nUE, variant=0), ob.Rng(ob.RNG_PHILOX, int(c.seed)), want_ues=k in want)
+
+    checked = [k for k, c in enumerate(cfgs) if int(c.seed) == 0 or (c.nUE == 100000 and int(c.seed) <= 4)]
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for k, (ores, oues) in ex.map(oracle, checked):
+            r = res[k]
+            bad = {f: (getattr(r, f), getattr(ores, f)) for f in KEYS if getattr(r, f) != getattr(ores, f)}
+            assert r.status == 0 and not bad and r.totalDelay == ores.totalDelay, (cfgs[k].nUE, int(cfgs[k].seed), bad)
+            if k in want:
+                assert_same(pkg, r, logs[k], ores, oues, ("grid", cfgs[k].nUE, int(cfgs[k].seed)))
+    for c, r in zip(cfgs, res):
+        n = c.nUE
+        assert r.status == 0 and r.nSuccessUE + r.failedUEs == n and r.activeCheck == n
+        assert (r.steps == 10000 and r.time_exit == 10000) or (r.nSuccessUE == n and r.steps == r.time_exit + 1)
+        assert 17 * r.nSuccessUE <= r.sumTimer <= 10000 * r.nSuccessUE and r.collisionPreambles <= r.totalPreambleTxop
+        if n <= 70000:
+            assert r.nSuccessUE == n  # 54 grants per 5 ms serve every UE of the small points (the reference's own sweep)
+    engine.set("batch_waves", 16)
+    try:
+        res16, _ = engine.run_trials(cfgs)
+    finally:
+        engine.set("batch_waves", 0)
+    assert [r.as_dict() for r in res16] == [r.as_dict() for r in res]
+
+
 def test_max_steps_and_stream_offset(pkg, ob, engine):
     cfg = pkg.make_cfg(8000, variant=1, rng_mode=0, seed=9, max_steps=2500)
     (res,), (logs,) = engine.run_trials([cfg], want_logs=True)
