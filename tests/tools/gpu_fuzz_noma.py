@@ -19,7 +19,7 @@ t0 = time.time()
 for k in range(ncase):
     nUE = int(rs.choice([1, 7, 64, 65, 500, 2000, 6000, 15000, 40000]))
     kw = dict(nPreamble=int(rs.choice([1, 2, 3, 8, 54, 64, 33])), backoff=int(rs.randint(1, 60)), nGrantUL=int(rs.choice([1, 2, 3, 5, 12, 40])),
-              maxRarWindow=int(rs.randint(1, 10)), maxMsg2TxCount=int(rs.choice([0, 1, 3, 10, 25])), accessTime=int(rs.choice([1, 2, 5, 5, 5, 8, 10])))
+              maxRarWindow=int(rs.randint(1, 10)), maxMsg2TxCount=int(rs.choice([0, 1, 3, 10, 25])), accessTime=int(rs.choice([1, 2, 5, 5, 5, 8, 10, 60])))
     if rs.rand() < 0.3:
         kw["max_steps"] = int(rs.randint(1, 6000))
     if rs.rand() < 0.3:
