@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NWB * 64, NWB == 8 ? PRACH_B_W8_WAVES : 4) void bat
         // ends in subframe t + k still has k - 1 subframes ahead.  One wavefront (lane = bucket) seeds this subframe's row with it; joins and events lower it further.
         for (int k = 1 + w; k <= 10; k += NWB) { // (a window ends at most maxRarWindow - 1 <= 10 subframes ahead; rows nothing ends in hold INT_MAX; one row per wavefront)
             const int v_ = BI(bl::ER)[((t + k) & (HRING - 1)) * NPB + lane];
-            atomicMin(&lds[lsel(lm(v_ != INT_MAX), bl::MR / 4 + (t & (HRING - 1)) * NPB + lane, bl::DUMMY / 4 + lane)], (v_ << 6) | (k - 1));
+            atomicMin(&lds[lsel(lm(v_ != INT_MAX), bl::MR / 4 + (t & (HRING - 1)) * NPB + lane, bl::DUMMY / 4 + lane)], (int)(((unsigned)v_ << 6) | (unsigned)(k - 1))); // (unsigned: an empty row holds INT_MAX, whose lane aims at the dummy word)
         }
         // ================= joins: UEs whose contention window opens in this subframe enter the histogram and the lowest-index tables =================
         { // (from the last wavefront down: the first ones have the most event batches; the next batch's entries are in flight while this one's atomics are issued)
