@@ -41,7 +41,11 @@ PRACH_HD int enc_backoff(int X, int t) { return X > 0 ? t + X : X; }
 // Philox4x32-10 (the draw = word 0 of the block >> 1).  Written for gfx950's instruction set: one v_mad_u64_u32 per 32 x 32 -> 64 product (the compiler
 // emits a v_mul_hi_u32 + v_mul_lo_u32 pair for __umulhi and *), one v_bitop3_b32 per three-way xor — 6 vector instructions per round instead of 10.  The
 // batched kernel is bound by instruction issue and the multiplies are its most expensive instructions (profiles/r04_grid.md, section 5).
+#ifdef PRACH_NO_BITOP3 // (diagnostic builds that switch the instruction off: LABNOTES, round 4)
+__device__ __forceinline__ unsigned xor3(const unsigned a, const unsigned b, const unsigned c) { return a ^ b ^ c; }
+#else
 __device__ __forceinline__ unsigned xor3(const unsigned a, const unsigned b, const unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+#endif
 __device__ __forceinline__ int philox_draw31(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2,
                                              unsigned c3) {
 #pragma unroll

@@ -265,6 +265,17 @@ PRACH_HD lmask lm(const bool c) { // v_cmp + v_cndmask: no scalar instruction
     return m;
 }
 PRACH_HD int lsel(const lmask m, const int a, const int b) { return (a & m) | (b & ~m); } // v_bfi_b32
+// A mask that leaves one of the functions below is made opaque again: the compiler folds trees of &, |, ~ into gfx950's three-input v_bitop3_b32, and ROCm 7.2's
+// selected a WRONG one when the plan's and the select's algebra were folded across the function boundary in one kernel shape (the build is bit-exact with the
+// instruction switched off, and with these barriers: LABNOTES, round 4).  With the barriers every tree lies inside one function, whatever the caller looks like —
+// and tests/tools/gpu_flat_equiv.hip runs exactly these functions on the device against the branched form.  Costs no instruction.
+PRACH_HD void lopaque(lmask &m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(m));
+#else
+    (void)m;
+#endif
+}
 PRACH_HD int fastmod_flat(const int x, const FastMod f) { // = fastmod
     const unsigned q = mulhi32((unsigned)x, f.M);
     const unsigned r = (unsigned)x - q * f.d;
@@ -314,6 +325,7 @@ PRACH_HD FlatPlan flat_plan(const UeState &u, const int t, const int maxRar, con
     const lmask m3due = lm(u.act == ACT_M3) & lm(u.tx == t), c0 = lm(u.conn == 0);
     p.m3first = m3due & c0; p.m3to = m3due & ~c0;
     p.need = (1 & (p.firstsel | p.retx | p.m3first)) | (2 & (p.reset | p.m3to));
+    lopaque(p.isM1); lopaque(p.pre0); lopaque(p.firstsel); lopaque(p.backoff); lopaque(p.reset); lopaque(p.retx); lopaque(p.stay); lopaque(p.m3first); lopaque(p.m3to);
     return p;
 }
 
@@ -368,6 +380,7 @@ PRACH_HD FlatOut flat_select(UeState &u, ColdRegs &cold, const FlatPlan &p, cons
     cold.fcnt = (cold.fcnt + (1 & withnoma & (p.reset | p.m3to))) & ~(withnoma & fs);
     c_contf += 1 & ((withnoma & p.reset) | p.m3to);
     c_succ += 1 & ok;
+    lopaque(o.member_pre); lopaque(o.eclass);
     return o;
 }
 
