@@ -1060,3 +1060,31 @@ def test_branch_free_event_body_equals_the_branched_form_on_the_device(tmp_path)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "tools", "gpu_flat_equiv.hip"), "-o", exe])
     p = subprocess.run([exe, "4000000", "21"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and " 0 differences" in p.stdout, p.stdout[-2000:]
+
+
+def test_library_without_bitop3_agrees():
+    """ROCm 7.2 folded a tree of the batched kernel's mask algebra into a WRONG v_bitop3_b32 in an experimental kernel shape (LABNOTES, round 4).  The shipped
+    shape is fenced (prach_ue_body.h: lopaque) and checked against the oracle elsewhere in this suite; here the same library built WITHOUT the instruction
+    (libprach_hip_nobitop3.so, `make NOBITOP3=1 lib`) must return the same results: 100-trial sweeps of both programs on the batched kernel in both workgroup
+    shapes — a difference means some kernel's results depend on how the compiler selected its boolean instructions."""
+    from conftest import ROOT
+    nb = os.path.join(ROOT, "5g-nr-randomaccess_amd", "libprach_hip_nobitop3.so")
+    if not os.path.exists(nb):
+        pytest.skip("libprach_hip_nobitop3.so not built")
+
+    def digests(lib):
+        out = []
+        for variant in ("0", "1"):
+            for waves in ("8", "16"):
+                env = dict(os.environ, PRACH_ENG_OPTS=f"batch_waves={waves}")
+                if lib:
+                    env["PRACH_LIB"] = lib
+                else:
+                    env.pop("PRACH_LIB", None)
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_batch.py"), "10", variant, "0"], env=env, capture_output=True, text=True, timeout=300)
+                assert p.returncode == 0 and "bad=0" in p.stdout, p.stdout[-500:] + p.stderr[-500:]
+                out.append(p.stdout.split("digest=")[1].split()[0])
+        return out
+
+    a, b = digests(None), digests(nb)
+    assert a == b and a[0] == a[1] and a[2] == a[3], (a, b)
