@@ -593,12 +593,13 @@ static int run_group(prach_engine *e, const prach_cfg *cfgs, const int *idx, int
         e->last.rec_mode = CLUSTER_REC_BATCH;
         e->last.xcd_packed = 0;
         // Workgroup shape (speed only, same results).  A launch is as long as its longest trial alone or as its work needs, whichever is more: a 100 000-UE
-        // trial runs 176 ms on 16 wavefronts and 228 ms on 8, so while the trials do not fill the CUs twice the 1024-thread shape wins (510 sweep trials:
-        // 193 / 370 ms — Beta.c / WithNOMA — against 235 / 419 ms); from there on two 512-thread workgroups = two trials per CU hide each other's
-        // barriers (1000 trials: 248 / 594 ms against 354 / 709 ms; 2000: 473 / 1 105 against 690 / 1 366): scripts/gpu_shape_probe.sh.
+        // trial runs 127 ms on 16 wavefronts and 152 ms on 8, so while the trials fit the CUs in two rounds the 1024-thread shape wins (510 sweep trials:
+        // 159 / 272 ms — Beta.c / WithNOMA — against 163 / 290 ms); past two per CU a third round starts, and two 512-thread workgroups = two trials per CU,
+        // which hide each other's barriers, win (560 trials: 165 / 288 against 171 / 294 ms; 740: 171 / 327 against 218 / 395; 1000: 207 / 442 against
+        // 288 / 517; 2000: 381 / 811 against 566 / 1 005): scripts/gpu_shape_probe.sh.
         int waves = (int)e->opt_batch_waves;
         if (rng_mode == PRACH_RNG_GLIBC) waves = 16;
-        if (waves == 0) waves = m >= 3 * e->num_cus ? 8 : 16;
+        if (waves == 0) waves = m > 2 * e->num_cus ? 8 : 16;
         e->last.workgroups = m;
         HIPCHK(launch_batch_kernel(reinterpret_cast<const TrialDev *>(A), m, waves, rng_mode == PRACH_RNG_GLIBC, e->stream));
     }
