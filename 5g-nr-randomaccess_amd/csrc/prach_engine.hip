@@ -929,6 +929,9 @@ static int run_trials_impl(prach_engine *e, const prach_cfg *cfgs, int n, prach_
                 // (in the reference's stream also against four workgroups per trial, which run on the general kernel: 50 trials 210 / 338 ms against 351 / 501 ms
                 //  at nUE = 100 000, 73 / 100 against 84 / 108 ms at 20 000; from eight workgroups per trial on the clusters are level or ahead)
                 if (G == 4 && all_batch && mode == PRACH_RNG_GLIBC) G = 1;
+                // (round 4's batch kernel is level with four workgroups per trial in Philox mode as well: 60 sweep trials 126 / 185 ms — Beta.c / WithNOMA — against
+                //  136 / 190 ms on 4-workgroup clusters; eight workgroups per trial stay ahead: 30 trials 95 / 118 against 126 / 184 ms)
+                if (G == 4 && all_batch) G = 1;
                 bool light = mode == PRACH_RNG_PHILOX;
                 for (int k : idx) light = light && cfgs[k].uniform && cfgs[k].nUE <= 2000000;
                 if (light) G = 1;
