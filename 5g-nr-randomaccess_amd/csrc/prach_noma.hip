@@ -342,9 +342,9 @@ __global__ __launch_bounds__(WG_THREADS) void noma_kernel(const TrialDev *__rest
                         // (lane i's 10 ln g through two v_readlane — i is wave-uniform — instead of a ds_bpermute round trip per comparison: this loop is a latency chain)
                         const double lgi10 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(clg10), i), __builtin_amdgcn_readlane(__double2loint(clg10), i));
                         const double diff = __dsub_rn(clg10, lgi10); // 10*log(high) - 10*log(low)
-                        const bool cond = lane > 0 && lane != i && ((valid >> lane) & 1ull) && diff > 15.0;
                         if (devact && lane < count && fabs(__dsub_rn(diff, 15.0)) < 1e-9) ambiguous = true; // (|error| of 10 ln g1 - 10 ln g2 < 1e-12)
-                        const unsigned long long mj = __ballot(cond);
+                        // (the lanes still unpaired, not lane 0, not i itself: scalar mask algebra on the comparison's ballot instead of a 64-bit shift per lane)
+                        const unsigned long long mj = __ballot(diff > 15.0) & valid & ~(1ull << i) & ~1ull;
                         if (!mj) continue;
                         const int j = __ffsll((long long)mj) - 1;
                         valid &= ~((1ull << i) | (1ull << j));
