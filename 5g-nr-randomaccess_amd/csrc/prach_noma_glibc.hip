@@ -142,13 +142,18 @@ __device__ __forceinline__ void noma_glibc_slot(NG NUe *const ue, const NG int *
             unsigned long long valid = count >= 64 ? ~0ull : ((1ull << count) - 1ull);
             int grants = 0;
             bool grantme = false;
-            for (int i = 0; i < count - 1; i++) { // NOMA.c:268-298 (enNoma stays 0: :266,269)
-                if (!((valid >> i) & 1ull)) continue;
-                const double lgi = __shfl(clg, i);
-                const double diff = __dsub_rn(__dmul_rn(10.0, clg), __dmul_rn(10.0, lgi)); // 10*log(high) - 10*log(low)
-                const bool cand = lane > 0 && lane != i && lane < count && ((valid >> lane) & 1ull);
-                if (devact && cand && fabs(__dsub_rn(diff, 15.0)) < 1e-9) ambiguous = true;
-                const unsigned long long mj = __ballot(cand && diff > 15.0);
+            const double clg10 = __dmul_rn(10.0, clg); // (NOMA.c:272: 10 * log(gain), the same product on either side of the difference)
+            const unsigned long long lows = count >= 2 ? ((1ull << (count - 1)) - 1ull) : 0ull; // i < count - 1
+            unsigned long long above = ~0ull;                                                    // bits behind the last i looked at
+            for (;;) { // NOMA.c:268-298 (enNoma stays 0: :266,269), over the still unpaired i in ascending order — as prach_noma.hip's resolver
+                const unsigned long long rest = valid & lows & above;
+                if (!rest) break;
+                const int i = __ffsll((long long)rest) - 1;
+                above = ~((2ull << i) - 1ull);
+                const double lgi10 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(clg10), i), __builtin_amdgcn_readlane(__double2loint(clg10), i));
+                const double diff = __dsub_rn(clg10, lgi10); // 10*log(high) - 10*log(low)
+                if (devact && lane < count && fabs(__dsub_rn(diff, 15.0)) < 1e-9) ambiguous = true; // (any singleton this close to the threshold: at worst one more rerun with the host's table)
+                const unsigned long long mj = __ballot(diff > 15.0) & valid & ~(1ull << i) & ~1ull;
                 if (!mj) continue;
                 const int j = __ffsll((long long)mj) - 1;
                 valid &= ~((1ull << i) | (1ull << j));
